@@ -1,0 +1,110 @@
+"""Synthetic tiles for parity tests and the bench (SURVEY.md section 8(d) recipe).
+
+There is no network and no trained ``model.pt`` in the build container, so the
+score maps a tile is sampled on are synthesised: a detection map with a narrow
+Gaussian bump on every ground-truth centre, and three 32-bin mark
+distributions that put 0.9 on the ground-truth class in a 7x7 window around
+each centre.  Array layouts match what the reference hands to its sampler
+(``models/mpp/data_loaders.py:48-55``): ``det`` is ``[H, W] float32`` and each
+mark map is ``[H, W, 32] float32``.
+
+Only ``numpy.random.Generator.random/integers/permutation/normal`` are used so
+the scenes are reproducible wherever this file runs.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+N_CLASSES = 32
+#: (v_min, v_max, cyclic) of the three marks; reference
+#: ``models/shape_net/shape_net_model.py:80-85``.
+MARK_RANGES = ((0.0, 32.0, False), (0.0, 1.0, False), (0.0, float(np.pi), True))
+
+
+def mark_edges() -> np.ndarray:
+    """``[3, 32] float64`` lower bin edges = ``linspace(vmin, vmax, 33)[:-1]``
+    (reference ``models/shape_net/mappings.py:16-17``)."""
+    return np.stack([np.linspace(lo, hi, N_CLASSES + 1)[:-1] for lo, hi, _ in MARK_RANGES])
+
+
+def wla_to_sra(a, b, angle):
+    """(width a, length b, angle) -> (size, ratio, angle); reference
+    ``base/shapes/rectangle.py:103-104``."""
+    return (a + b) / 2, a / b, angle
+
+
+def value_to_class(values: np.ndarray, edges: np.ndarray) -> np.ndarray:
+    """max{i : v >= edge_i}  (reference ``mappings.py:54-55``)."""
+    return np.maximum(np.searchsorted(edges, values, side="right") - 1, 0)
+
+
+@dataclass
+class SynthTile:
+    shape: Tuple[int, int]
+    det: np.ndarray            # [H, W] float32
+    marks: List[np.ndarray]    # 3 x [H, W, 32] float32
+    gt_xy: np.ndarray          # [N, 2] int32 (row, col)
+    gt_marks: np.ndarray       # [N, 3] float64 (size, ratio, angle)
+
+
+def make_gt(tile: int, n_objects: int, tile_id: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+    rng = np.random.default_rng(1234 + tile_id)
+    lattice = np.arange(10, tile - 10, 14)
+    n_cells = len(lattice) ** 2
+    n_objects = min(n_objects, n_cells)
+    pick = rng.permutation(n_cells)[:n_objects]
+    cx = lattice[pick // len(lattice)] + rng.integers(-2, 3, size=n_objects)
+    cy = lattice[pick % len(lattice)] + rng.integers(-2, 3, size=n_objects)
+    a = rng.normal(4.5, 0.4, size=n_objects)
+    b = rng.normal(9.0, 0.8, size=n_objects)
+    theta = rng.random(n_objects) * np.pi
+    size, ratio, angle = wla_to_sra(a, b, theta)
+    xy = np.stack([cx, cy], axis=1).astype(np.int32)
+    marks = np.stack([size, np.clip(ratio, 0.05, 1.0), angle], axis=1)
+    return xy, marks
+
+
+def render_maps(shape: Tuple[int, int], gt_xy: np.ndarray, gt_marks: np.ndarray,
+                noise: float = 0.0, noise_seed: int = 0) -> Tuple[np.ndarray, List[np.ndarray]]:
+    """Score maps for a set of ground-truth rectangles.
+
+    ``noise`` > 0 mixes seeded uniform noise into the mark distributions (then
+    renormalises each 32-bin row) so that data-driven proposals see non-trivial
+    probabilities; 0 gives the plain SURVEY recipe."""
+    H, W = shape
+    det = np.full((H, W), 0.02, dtype=np.float64)
+    R = 5
+    for (x, y) in gt_xy:
+        x0, x1 = max(0, x - R), min(H, x + R + 1)
+        y0, y1 = max(0, y - R), min(W, y + R + 1)
+        xx, yy = np.mgrid[x0:x1, y0:y1]
+        bump = np.exp(-((xx - x) ** 2 + (yy - y) ** 2) / (2 * 1.2 ** 2))
+        det[x0:x1, y0:y1] = np.maximum(det[x0:x1, y0:y1], bump)
+    det = det.astype(np.float32)
+
+    edges = mark_edges()
+    marks = []
+    nrng = np.random.default_rng(noise_seed)
+    for k in range(3):
+        m = np.full((H, W, N_CLASSES), 1.0 / N_CLASSES, dtype=np.float32)
+        cls = value_to_class(gt_marks[:, k], edges[k])
+        for (x, y), c in zip(gt_xy, cls):
+            x0, x1 = max(0, x - 3), min(H, x + 4)
+            y0, y1 = max(0, y - 3), min(W, y + 4)
+            m[x0:x1, y0:y1, :] = np.float32(0.1 / (N_CLASSES - 1))
+            m[x0:x1, y0:y1, c] = np.float32(0.9)
+        if noise > 0:
+            m = m + np.float32(noise) * nrng.random(m.shape, dtype=np.float32)
+            m = m / m.sum(axis=-1, keepdims=True, dtype=np.float32)
+        marks.append(np.ascontiguousarray(m, dtype=np.float32))
+    return det, marks
+
+
+def make_tile(tile: int = 512, n_objects: int = 200, tile_id: int = 0, noise: float = 0.0) -> SynthTile:
+    """The SURVEY 8(d) synthetic tile: config 1 is (256, 50), config 2 is (512, 200)."""
+    gt_xy, gt_marks = make_gt(tile, n_objects, tile_id)
+    det, marks = render_maps((tile, tile), gt_xy, gt_marks, noise=noise, noise_seed=77 + tile_id)
+    return SynthTile(shape=(tile, tile), det=det, marks=marks, gt_xy=gt_xy, gt_marks=gt_marks)
