@@ -1,0 +1,315 @@
+"""Energy setups and combinators of the MPP model, as flat term tables.
+
+The reference wires Python objects: ``EnergySetup.make_energies`` returns lists
+of unit / pair energy constructors (``models/mpp/energies/energy_setups/*.py``)
+and an ``EnergyCombinationModel`` folds the per-point energy vectors into a
+scalar (``models/mpp/energies/combination/*.py``).  The HIP sampler cannot call
+Python per point, so the same classes here *describe* their terms; the
+description is flattened into :class:`ModelDesc`, which is what crosses the
+C ABI (``include/mpp_hip.h``: ``mpp_model``).
+
+Every combinator the two shipped configs use has the form
+
+    E(x) = sum_u F( lin0 + sum_k coef_k * g_k(u) * v_k(u) ),
+    g_k = [v_gate(u) <= thr] if term k is gated else 1,  F = id  or  2*sigmoid-1
+
+(hierarchical.py:21-32, :41-48; logistic.py:20-26), so ``ModelDesc`` stores one
+coefficient and one gate flag per term.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+# unit term kinds (same numbering as include/mpp_hip.h)
+U_POSITION, U_SHAPE_REMAP, U_MARK_NEG, U_MARK_REMAP, U_AREA, U_RATIO_PRIOR, U_CONST = range(7)
+# pair term kinds
+P_OVERLAP, P_ALIGN, P_DIST_LE, P_DIST_LT = range(4)
+REDUCE_MAX, REDUCE_MIN = 0, 1
+C_LINEAR, C_LOGISTIC = 0, 1
+MAX_UNIT, MAX_PAIR = 8, 2
+
+
+@dataclass
+class UnitTerm:
+    """One unit energy (reference ``UnitEnergyConstructor``, base_energies.py:8-27)."""
+    name: str
+    kind: int
+    params: Sequence[float] = ()
+
+
+@dataclass
+class PairTerm:
+    """One pair energy (reference ``PairEnergyConstructor``, base_energies.py:42-69)."""
+    name: str
+    kind: int
+    max_dist: float
+    reduce: int = REDUCE_MAX
+    params: Sequence[float] = ()
+
+
+@dataclass
+class ModelDesc:
+    unit: List[Tuple[int, int, float, Tuple[float, ...]]]         # (kind, gated, coef, params)
+    pair: List[Tuple[int, int, int, float, float, Tuple[float, ...]]]  # (kind, gated, reduce, coef, max_dist, params)
+    combinator: int = C_LINEAR
+    gate_term: int = -1
+    gate_thr: float = 0.0
+    lin0: float = 0.0
+    names: List[str] = field(default_factory=list)
+
+    @property
+    def n_terms(self) -> int:
+        return len(self.unit) + len(self.pair)
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+# --------------------------------------------------------------------------- combinators
+class EnergyCombinationModel:
+    """Reference ``custom_types/energy.py:8-11``."""
+
+    def compute(self, vectors: Dict[str, Sequence[float]]) -> float:
+        raise NotImplementedError
+
+    def coefficients(self, names: Sequence[str]):
+        """-> (combinator, coef per name, gated per name, gate_name or None, gate_thr, lin0)."""
+        raise NotImplementedError
+
+
+@dataclass
+class HierarchicalEnergyCombinator(EnergyCombinationModel):
+    """Reference ``combination/hierarchical.py:13-32``."""
+    weights_data: np.ndarray
+    weights_prior: np.ndarray
+    data_prior_weights: np.ndarray
+    detection_threshold: float
+    bias: float = 0.0
+
+    def compute(self, vectors):
+        pos = np.asarray(vectors["PositionEnergy"], dtype=float)
+        ind = pos <= self.detection_threshold
+        data = self.weights_data[0] * pos + ind * (self.weights_data[1] * np.asarray(vectors["ShapeEnergy"], float))
+        prior = ind * (self.weights_prior[0] * np.asarray(vectors["RectangleOverlapEnergy"], float)
+                       + self.weights_prior[1] * np.asarray(vectors["ShapeAlignmentEnergy"], float)
+                       + self.weights_prior[2] * np.asarray(vectors["AreaPriorEnergy"], float))
+        return float(np.sum(self.data_prior_weights[0] * data + self.data_prior_weights[1] * prior + self.bias))
+
+    def coefficients(self, names):
+        wd, wp, dp = (np.asarray(a, dtype=float) for a in (self.weights_data, self.weights_prior,
+                                                             self.data_prior_weights))
+        table = {
+            "PositionEnergy": (dp[0] * wd[0], 0),
+            "ShapeEnergy": (dp[0] * wd[1], 1),
+            "RectangleOverlapEnergy": (dp[1] * wp[0], 1),
+            "ShapeAlignmentEnergy": (dp[1] * wp[1], 1),
+            "AreaPriorEnergy": (dp[1] * wp[2], 1),
+        }
+        missing = [n for n in names if n not in table]
+        if missing:
+            raise KeyError(f"HierarchicalEnergyCombinator has no weight for {missing}")
+        return (C_LINEAR, [table[n][0] for n in names], [table[n][1] for n in names], "PositionEnergy",
+                float(self.detection_threshold), float(self.bias))
+
+
+@dataclass
+class ManualHierarchicalEnergyCombinator(EnergyCombinationModel):
+    """Reference ``combination/hierarchical.py:35-48``."""
+    weights_dict: Dict[str, float]
+    indicator_energy: str
+    detection_threshold: float = 0.0
+
+    def compute(self, vectors):
+        ind_v = np.asarray(vectors[self.indicator_energy], dtype=float)
+        ind = ind_v <= self.detection_threshold
+        rest = sum(w * np.asarray(vectors[k], float) for k, w in self.weights_dict.items()
+                   if k != self.indicator_energy)
+        return float(np.sum(self.weights_dict[self.indicator_energy] * ind_v + ind * rest))
+
+    def coefficients(self, names):
+        coef = [float(self.weights_dict.get(n, 0.0)) for n in names]
+        gated = [0 if n == self.indicator_energy else 1 for n in names]
+        return C_LINEAR, coef, gated, self.indicator_energy, float(self.detection_threshold), 0.0
+
+
+@dataclass
+class LogisticEnergyCombinator(EnergyCombinationModel):
+    """Reference ``combination/logistic.py:14-26`` (the bias enters once per term)."""
+    weights: np.ndarray
+    bias: float
+    energy_names: List[str]
+
+    def compute(self, vectors):
+        v = np.array([vectors[k] for k in self.energy_names], dtype=float).T
+        if len(v) == 0:
+            return 0.0
+        return float(np.sum(2 * sigmoid(np.sum(self.bias + np.asarray(self.weights, float) * v, axis=-1)) - 1))
+
+    def coefficients(self, names):
+        w = {n: float(x) for n, x in zip(self.energy_names, np.asarray(self.weights, dtype=float))}
+        return (C_LOGISTIC, [w[n] for n in names], [0] * len(names), None, 0.0,
+                float(self.bias) * len(self.energy_names))
+
+
+def build_model_desc(unit_terms: Sequence[UnitTerm], pair_terms: Sequence[PairTerm],
+                     combinator: Optional[EnergyCombinationModel]) -> ModelDesc:
+    """Flatten (unit terms, pair terms, combinator) for the C ABI.  ``combinator=None`` is the
+    plain sum the reference uses when no combinator is passed (energy_graph.py:130-131)."""
+    if len(unit_terms) > MAX_UNIT or len(pair_terms) > MAX_PAIR:
+        raise ValueError(f"at most {MAX_UNIT} unit and {MAX_PAIR} pair terms")
+    names = [t.name for t in unit_terms] + [t.name for t in pair_terms]
+    if len(set(names)) != len(names):
+        raise AssertionError(f"duplicate energy names in {names}")      # energy_graph.py:37-42
+    if combinator is None:
+        kind, coef, gated, gate_name, thr, lin0 = C_LINEAR, [1.0] * len(names), [0] * len(names), None, 0.0, 0.0
+    else:
+        kind, coef, gated, gate_name, thr, lin0 = combinator.coefficients(names)
+    nu = len(unit_terms)
+    gate_term = -1
+    if gate_name is not None:
+        gate_term = names.index(gate_name)
+        if gate_term >= nu:
+            raise ValueError("the gating energy must be a unit term")
+    unit = [(t.kind, int(gated[i]), float(coef[i]), tuple(float(p) for p in t.params))
+            for i, t in enumerate(unit_terms)]
+    pair = [(t.kind, int(gated[nu + i]), int(t.reduce), float(coef[nu + i]), float(t.max_dist),
+             tuple(float(p) for p in t.params)) for i, t in enumerate(pair_terms)]
+    return ModelDesc(unit=unit, pair=pair, combinator=kind, gate_term=gate_term, gate_thr=thr, lin0=lin0,
+                     names=names)
+
+
+# --------------------------------------------------------------------------- setups
+class EnergySetup:
+    """Reference ``energies/energy_utils.py:14-37``."""
+
+    @property
+    def energy_names(self) -> List[str]:
+        raise NotImplementedError
+
+    def make_energies(self, image_data=None) -> Tuple[List[UnitTerm], List[PairTerm]]:
+        raise NotImplementedError
+
+    def load_calibration(self, save_dir: str):
+        raise NotImplementedError
+
+    @property
+    def detection_threshold(self) -> float:
+        raise NotImplementedError
+
+
+class LegacyEnergySetup(EnergySetup):
+    """Reference ``energy_setups/energy_setup_legacy.py:34-139``: 3 unit + 2 pair terms."""
+    NAMES = ["PositionEnergy", "ShapeEnergy", "RectangleOverlapEnergy", "ShapeAlignmentEnergy", "AreaPriorEnergy"]
+
+    def __init__(self, calibration_params=None, rewarding_priors: bool = True, energy_calibration: dict = None):
+        self.calibration_params = calibration_params or {}
+        self.rewarding_priors = rewarding_priors
+        self.energy_calibration = energy_calibration
+
+    @property
+    def energy_names(self):
+        return list(self.NAMES)
+
+    def load_calibration(self, save_dir: str):
+        with open(os.path.join(save_dir, "calibration.json")) as f:
+            d = json.load(f)
+        self.energy_calibration = {k: d[k] for k in ("detection_threshold", "param_dist_remap_coefs",
+                                                     "param_dist_remap_intercepts", "min_area", "max_area")}
+
+    @property
+    def detection_threshold(self):
+        return float(self.energy_calibration["detection_threshold"])
+
+    def make_energies(self, image_data=None):
+        c = self.energy_calibration
+        unit = [
+            UnitTerm(self.NAMES[0], U_POSITION, [c["detection_threshold"]]),
+            UnitTerm(self.NAMES[1], U_SHAPE_REMAP, list(c["param_dist_remap_coefs"]) +
+                     list(c["param_dist_remap_intercepts"])),
+            UnitTerm(self.NAMES[4], U_AREA, [c["min_area"], c["max_area"]]),
+        ]
+        pair = [
+            PairTerm(self.NAMES[2], P_OVERLAP, max_dist=32.0, reduce=REDUCE_MAX),
+            PairTerm(self.NAMES[3], P_ALIGN, max_dist=16.0,
+                     reduce=REDUCE_MIN if self.rewarding_priors else REDUCE_MAX,
+                     params=[1.0 if self.rewarding_priors else 0.0]),
+        ]
+        return unit, pair
+
+
+class NoCalibrationEnergySetup(EnergySetup):
+    """Reference ``energy_setups/energy_setup_no_calibration.py:31-159``."""
+
+    def __init__(self, rewarding_priors: bool = True, ratio_prior: bool = False, calib_marks: bool = False):
+        self.energy_calibration = None
+        self.rewarding_priors = rewarding_priors
+        self.ratio_prior = ratio_prior
+        self.calib_marks = calib_marks
+        self.NAMES = ["PositionEnergy", "SizeEnergy", "RatioEnergy", "AngleEnergy", "OverlapPriorEnergy",
+                      "AlignmentPriorEnergy", "AreaPriorEnergy"]
+        if ratio_prior:
+            self.NAMES.append("RatioPriorEnergy")
+
+    @property
+    def energy_names(self):
+        return list(self.NAMES)
+
+    def load_calibration(self, save_dir: str):
+        with open(os.path.join(save_dir, "calibration.json")) as f:
+            d = json.load(f)
+        self.energy_calibration = {"min_area": d["min_area"], "max_area": d["max_area"],
+                                   "param_dist_remap_coefs": d.get("param_dist_remap_coefs"),
+                                   "param_dist_remap_intercepts": d.get("param_dist_remap_intercepts")}
+
+    @property
+    def detection_threshold(self):
+        return 0.5
+
+    def make_energies(self, image_data=None):
+        c = self.energy_calibration
+        unit = [UnitTerm(self.NAMES[0], U_POSITION, [0.0])]
+        for k in range(3):
+            if self.calib_marks:
+                unit.append(UnitTerm(self.NAMES[1 + k], U_MARK_REMAP,
+                                     [k, c["param_dist_remap_coefs"][k], c["param_dist_remap_intercepts"][k]]))
+            else:
+                unit.append(UnitTerm(self.NAMES[1 + k], U_MARK_NEG, [k]))
+        unit.append(UnitTerm(self.NAMES[6], U_AREA, [c["min_area"], c["max_area"]]))
+        if self.ratio_prior:
+            unit.append(UnitTerm(self.NAMES[7], U_RATIO_PRIOR, [0.5]))
+        pair = [
+            PairTerm(self.NAMES[4], P_OVERLAP, max_dist=32.0, reduce=REDUCE_MAX),
+            PairTerm(self.NAMES[5], P_ALIGN, max_dist=16.0,
+                     reduce=REDUCE_MIN if self.rewarding_priors else REDUCE_MAX,
+                     params=[1.0 if self.rewarding_priors else 0.0]),
+        ]
+        return unit, pair
+
+    def ordered_terms(self):
+        """Terms in ``energy_names`` order (unit and pair terms interleave in the reference's name list)."""
+        unit, pair = self.make_energies()
+        by_name = {t.name: t for t in unit + pair}
+        return [by_name[n] for n in self.NAMES]
+
+
+def normalize_l1(values: Sequence[float]) -> np.ndarray:
+    """``utils/math_utils.py:45-49`` with l=1."""
+    a = np.asarray(values, dtype=float)
+    return a / np.sum(np.abs(a))
+
+
+def hierarchical_from_manual(manual: Dict[str, float]) -> HierarchicalEnergyCombinator:
+    """The ``manual`` train mode for the legacy setup (reference ``mpp_model.py:155-175``):
+    each weight group is L1-normalised."""
+    return HierarchicalEnergyCombinator(
+        weights_data=normalize_l1([manual["PositionEnergy"], manual["ShapeEnergy"]]),
+        weights_prior=normalize_l1([manual["RectangleOverlapEnergy"], manual["ShapeAlignmentEnergy"],
+                                    manual["AreaPriorEnergy"]]),
+        data_prior_weights=normalize_l1([manual["Data"], manual["Prior"]]),
+        detection_threshold=float(manual.get("threshold", 0.0)))

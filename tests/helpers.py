@@ -1,0 +1,115 @@
+"""Shared helpers for the test-suite: fixture loading and tape -> proposal conversion."""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from mpp_cnn_rs_object_detection_amd import energies, kernels, mappings, synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PROPOSAL_DTYPE = np.dtype([("kernel", "<i4"), ("target", "<i4"), ("ax", "<i4"), ("ay", "<i4"),
+                           ("as", "<f8"), ("ar", "<f8"), ("aa", "<f8"), ("aux0", "<f8"), ("aux1", "<f8"),
+                           ("param_id", "<i4"), ("new_class", "<i4"), ("u_accept", "<f8")], align=True)
+
+
+def load_json(*parts):
+    with open(os.path.join(REPO, *parts)) as f:
+        return json.load(f)
+
+
+def hrc_model():
+    setup = energies.LegacyEnergySetup()
+    setup.load_calibration(os.path.join(REPO, "models_storage", "mpp", "mpp_hrcM"))
+    comb = energies.hierarchical_from_manual(load_json("model_configs", "mpp", "mpp_hrcM.json")["manual"])
+    return setup, comb
+
+
+def log_model():
+    setup = energies.NoCalibrationEnergySetup(ratio_prior=True)
+    setup.load_calibration(os.path.join(REPO, "models_storage", "mpp", "mpp_log"))
+    j = load_json("models_storage", "mpp", "mpp_log", "energy_combination_model.json")
+    comb = energies.LogisticEnergyCombinator(weights=np.array(j["weights"], dtype=np.float32), bias=j["bias"],
+                                             energy_names=j["energy_names"])
+    return setup, comb
+
+
+def model_for(setup_name: str):
+    setup, comb = hrc_model() if setup_name == "legacy" else log_model()
+    unit, pair = setup.make_energies()
+    return setup, comb, energies.build_model_desc(unit, pair, comb)
+
+
+class Tape:
+    """A recorded reference chain (tests/golden/tape_*.npz) turned into replayable proposals."""
+
+    def __init__(self, name: str):
+        z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+        self.shape = tuple(int(v) for v in z["shape"])
+        self.det = z["det"]
+        _, self.marks = synth.render_maps(self.shape, z["gt_xy"], z["gt_marks"], noise=float(z["noise"]),
+                                          noise_seed=int(z["noise_seed"]))
+        self.setup_name = str(z["setup"])
+        self.params = json.loads(str(z["params"]))
+        self.cols = {c: i for i, c in enumerate(z["columns"])}
+        self.raw = z["tape"]
+        self.init = z["init"]
+        self.final = z["final"]
+        self.p_kernels = z["p_kernels"]
+        self.intensity = float(z["intensity"])
+        self.E0 = float(z["E0"])
+        self.setup, self.comb, self.model = model_for(self.setup_name)
+        self.kernels = kernels.make_kernels(mappings.default_mappings(), self.intensity)
+        self.proposals = self._proposals()
+
+    def col(self, name):
+        return self.raw[:, self.cols[name]]
+
+    @property
+    def init_xy(self):
+        return self.init[:, :2].astype(np.int32)
+
+    @property
+    def init_marks(self):
+        return np.ascontiguousarray(self.init[:, 2:5], dtype=np.float64)
+
+    def _proposals(self):
+        """Translate point identities into slots under the canonical slot discipline
+        (birth appends, death swap-removes, move rewrites in place), following the REFERENCE's
+        accept decisions."""
+        state = [tuple(r) for r in self.init]
+        out = np.zeros(len(self.raw), PROPOSAL_DTYPE)
+        c = self.cols
+        for i, row in enumerate(self.raw):
+            rem = tuple(row[c["rx"]:c["rx"] + 5])
+            add = tuple(row[c["ax"]:c["ax"] + 5])
+            has_rem, has_add = not np.isnan(rem[0]), not np.isnan(add[0])
+            p = out[i]
+            p["kernel"] = int(row[c["kernel"]])
+            p["target"] = state.index(rem) if has_rem else -1
+            if has_add:
+                p["ax"], p["ay"], p["as"], p["ar"], p["aa"] = int(add[0]), int(add[1]), add[2], add[3], add[4]
+            p["aux0"] = 0.0 if np.isnan(row[c["delta0"]]) else row[c["delta0"]]
+            p["aux1"] = 0.0 if np.isnan(row[c["delta1"]]) else row[c["delta1"]]
+            p["param_id"] = int(row[c["param_id"]])
+            p["new_class"] = int(row[c["new_class"]])
+            p["u_accept"] = row[c["u_accept"]]
+            if row[c["accepted"]] > 0:
+                if has_rem and has_add:
+                    state[p["target"]] = add
+                elif has_rem:
+                    t = p["target"]
+                    state[t] = state[-1]
+                    state.pop()
+                elif has_add:
+                    state.append(add)
+        self.final_by_slots = np.array(state, dtype=float).reshape(-1, 5)
+        return out
+
+
+def sorted_rows(a):
+    a = np.asarray(a, dtype=float).reshape(-1, 5)
+    return a[np.lexsort(a.T[::-1])] if len(a) else a

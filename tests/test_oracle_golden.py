@@ -1,0 +1,95 @@
+"""The C oracle against vectors recorded from the reference itself (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import GOLDEN, Tape, model_for, sorted_rows
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import synth
+
+TAPES = ["tape_hrc_64.npz", "tape_log_96.npz", "tape_hrc_128_gt.npz", "tape_log_64_empty.npz"]
+# energies are float64 sums of float32 map reads; the reference does part of the arithmetic in float32
+DE_ATOL, DE_RTOL, P_RTOL = 2e-6, 2e-6, 2e-5
+TIE = 1e-5   # |log u - log alpha| below which an accept decision may legitimately differ
+
+
+def make_oracle(t: Tape):
+    o = oracle.Oracle(t.shape, t.det, t.marks, t.model, t.kernels)
+    o.set_points(t.init_xy, t.init_marks)
+    return o
+
+
+@pytest.mark.parametrize("name", TAPES)
+def test_tape_replay(name):
+    t = Tape(name)
+    assert np.allclose(t.kernels.p_kernel, t.p_kernels, rtol=0, atol=1e-15)
+    o = make_oracle(t)
+    assert o.total_energy() == pytest.approx(t.E0, rel=1e-6, abs=1e-6)
+    p = t.params
+    o.set_temperature(p["init_temperature"], p["alpha_t"], p["target_temperature"])
+    out = o.replay(t.proposals)
+    ref_acc = t.col("accepted").astype(int)
+    margin = np.abs(np.log(t.col("u_accept") + 1e-16) - out["log_alpha"])
+    disagree = np.nonzero(out["accepted"] != ref_acc)[0]
+    assert all(margin[i] < TIE for i in disagree), f"accept decisions differ at {disagree[:5]}"
+    assert len(disagree) == 0, "a near-tie flipped; regenerate the tape or raise the tolerance consciously"
+    np.testing.assert_allclose(out["T"], t.col("T"), rtol=1e-12)
+    np.testing.assert_array_equal(out["n_after"], t.col("n_after").astype(int))
+    np.testing.assert_allclose(out["dE"], t.col("dE"), rtol=DE_RTOL, atol=DE_ATOL)
+    np.testing.assert_allclose(out["fwd"], t.col("fwd"), rtol=P_RTOL, atol=1e-300)
+    np.testing.assert_allclose(out["bwd"], t.col("bwd"), rtol=P_RTOL, atol=1e-300)
+    xy, marks = o.get_points()
+    got = np.concatenate([xy.astype(float), marks], axis=1)
+    np.testing.assert_array_equal(sorted_rows(got), sorted_rows(t.final_by_slots))
+    if p["samples_interval"] == 1:   # the returned sample is then the last state of the chain
+        np.testing.assert_array_equal(sorted_rows(got), sorted_rows(t.final))
+
+
+@pytest.mark.parametrize("name", ["tape_hrc_64.npz", "tape_log_96.npz"])
+def test_naive_detection_matches_reference_init(name):
+    t = Tape(name)
+    o = make_oracle(t)
+    xy, marks = o.naive_detection(t.setup.detection_threshold, 6.0)
+    got = np.concatenate([xy.astype(float), marks], axis=1)
+    np.testing.assert_allclose(sorted_rows(got), sorted_rows(t.init), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag,setup_name", [("hrc", "legacy"), ("log", "no-calibration")])
+def test_delta_cases(tag, setup_name):
+    z = np.load(f"{GOLDEN}/delta_cases.npz", allow_pickle=False)
+    g = lambda k: z[f"{tag}_{k}"]
+    det = g("det")
+    _, marks = synth.render_maps(det.shape, g("gt_xy"), g("gt_marks"), noise=float(z["noise"]),
+                                 noise_seed=int(z["noise_seed"]))
+    setup, comb, model = model_for(setup_name)
+    base = g("base")
+    o = oracle.Oracle(det.shape, det, marks, model)
+    o.set_points(base[:, :2].astype(np.int32), base[:, 2:])
+    e0, vec = o.total_energy(return_vectors=True)
+    assert e0 == pytest.approx(float(g("E0")), rel=1e-6, abs=1e-6)
+    ref_names = [str(n) for n in g("names")]
+    order = [o.names.index(n) for n in ref_names]
+    np.testing.assert_allclose(vec[:, order], g("vec"), rtol=2e-6, atol=2e-6)
+    # plain sum (no combinator): energy_graph.py:130-131
+    unit, pair = setup.make_energies()
+    o_sum = oracle.Oracle(det.shape, det, marks, E.build_model_desc(unit, pair, None))
+    o_sum.set_points(base[:, :2].astype(np.int32), base[:, 2:])
+    assert o_sum.total_energy() == pytest.approx(float(g("E0_sum")), rel=1e-6, abs=1e-5)
+    np.testing.assert_allclose(o.papangelou(), g("papangelou_dE"), rtol=2e-6, atol=2e-6)
+
+    rows = [tuple(r) for r in base]
+    add_off = np.concatenate([[0], np.cumsum(g("add_len"))])
+    rem_off = np.concatenate([[0], np.cumsum(g("rem_len"))])
+    for i, (d_ref, e1_ref) in enumerate(zip(g("dE"), g("E1"))):
+        add = g("add_flat")[add_off[i]:add_off[i + 1]]
+        rem = g("rem_flat")[rem_off[i]:rem_off[i + 1]]
+        slots = [rows.index(tuple(r)) for r in rem]
+        d = o.delta(removal_slots=slots, add_xy=add[:, :2].astype(np.int32), add_marks=add[:, 2:])
+        assert d == pytest.approx(float(d_ref), rel=2e-6, abs=5e-6), f"case {i}"
+        keep = [r for j, r in enumerate(rows) if j not in slots] + [tuple(r) for r in add]
+        new = np.array(keep, dtype=float).reshape(-1, 5)
+        o2 = oracle.Oracle(det.shape, det, marks, model)
+        o2.set_points(new[:, :2].astype(np.int32), new[:, 2:])
+        e1 = o2.total_energy()
+        assert e1 == pytest.approx(float(e1_ref), rel=1e-6, abs=5e-6)
+        assert abs(d - (e1 - e0)) < 1e-8    # the reference's own criterion, test_perturbation_sampler.py:99
