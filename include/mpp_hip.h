@@ -1,0 +1,172 @@
+/*
+ * mpp_hip.h -- C ABI of libmppgpu.so, the MI355X (gfx950) implementation of the
+ * MPP / RJMCMC sampling path of Ayana-Inria/MPP_CNN_RS_object_detection.
+ *
+ * The reference has no FFI: its boundary is a set of Python call signatures.
+ * Each entry point below names the reference interface it stands behind
+ * (paths relative to the reference repository root).  The Python binding that
+ * mirrors those signatures is mpp_cnn_rs_object_detection_amd/{hip_api,point_set,sampler}.py;
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - every call returns 0 on success, <0 on error; mpp_last_error(ctx) has the text;
+ *  - the caller owns every host buffer; the library owns device memory for the
+ *    lifetime of the ctx; pointers passed with on_device=1 are borrowed, never freed;
+ *  - a ctx is bound to one GPU and one HIP stream and is not thread-safe; distinct
+ *    ctxs are independent; no global state, no callbacks, no Python objects;
+ *  - a ctx holds n_tiles independent tiles of identical H x W ("tiles" are the
+ *    reference's 256-px patches, models/mpp/mpp_model.py:231-248); one workgroup
+ *    samples one tile.
+ *  - "slot": points of a tile are kept in dense slots 0..n-1 (birth appends, death
+ *    moves the last slot into the hole, move/transform rewrites in place).
+ */
+#ifndef MPP_HIP_H
+#define MPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPP_MAX_UNIT 8
+#define MPP_MAX_PAIR 2
+#define MPP_NCLASS 32
+#define MPP_NKERNEL 8
+
+/* unit energies: models/mpp/energies/data_energies.py, prior_energies.py */
+enum {
+  MPP_U_POSITION = 0,    /* p[0]=thr: -2*(det[x,y]-thr)                       data_energies.py:12-24   */
+  MPP_U_SHAPE_REMAP = 1, /* p[0..2]=coef p[3..5]=icpt: mean_k(-2*sigmoid(coef_k*P_k+icpt_k)+1)
+                            data_energies.py:27-45 + energy_setup_legacy.py:142-147                     */
+  MPP_U_MARK_NEG = 2,    /* p[0]=k: -P_k[x,y,class_k]            energy_setup_no_calibration.py:68-80  */
+  MPP_U_MARK_REMAP = 3,  /* p[0]=k p[1]=coef p[2]=icpt           (calib_marks=True)                     */
+  MPP_U_AREA = 4,        /* p[0]=min p[1]=max: max(0,min-A,A-max)             prior_energies.py:53-67  */
+  MPP_U_RATIO_PRIOR = 5, /* p[0]=target: |target-ratio|                       prior_energies.py:70-78  */
+  MPP_U_CONST = 6        /* p[0]=c (the unit energy of the reference's unit tests)                      */
+};
+/* pair energies: prior_energies.py */
+enum {
+  MPP_P_OVERLAP = 0,     /* area(P1^P2)/(min(A1,A2)+1e-6), reduce max         prior_energies.py:11-24  */
+  MPP_P_ALIGN = 1,       /* 1-|cos(a1-a2)|-rewarding; p[0]=rewarding          prior_energies.py:27-50  */
+  MPP_P_DIST_LE = 2,     /* [d<=max_dist]  (test/test_energy_graph.py:26-37)                            */
+  MPP_P_DIST_LT = 3      /* [d< max_dist]  (test/test_interacting_points_set.py:30-42)                  */
+};
+enum { MPP_REDUCE_MAX = 0, MPP_REDUCE_MIN = 1 };
+/* E(x) = sum_u F(lin0 + sum_k coef_k*g_k*v_k(u)); g_k=[v_gate<=gate_thr] if gated else 1.
+ * F=identity: combination/hierarchical.py:13-48 and the plain sum of energy_graph.py:130-131;
+ * F=2*sigmoid-1: combination/logistic.py:14-26. */
+enum { MPP_C_LINEAR = 0, MPP_C_LOGISTIC = 1 };
+
+typedef struct { int32_t kind, gated; double coef; double p[8]; } mpp_unit_term;
+typedef struct { int32_t kind, gated, reduce, _pad; double coef, max_dist; double p[2]; } mpp_pair_term;
+
+/* what EnergySetup.make_energies + an EnergyCombinationModel amount to
+ * (energies/energy_setups/ and energies/combination/) */
+typedef struct {
+  int32_t n_unit, n_pair, combinator, gate_term;
+  double gate_thr, lin0;
+  mpp_unit_term unit[MPP_MAX_UNIT];
+  mpp_pair_term pair[MPP_MAX_PAIR];
+} mpp_model;
+
+/* the three ValueMappings (models/shape_net/mappings.py:9-74): lower bin edges and ranges */
+typedef struct {
+  int32_t cyclic[3], _pad;
+  double vmin[3], vmax[3];
+  double edges[3][MPP_NCLASS];
+} mpp_mappings;
+
+/* kernel mixture, rjmcmc_sampler/kernels/make_kernels.py:50-177 (same order as its list) */
+enum { MPP_K_UBIRTH = 0, MPP_K_UDEATH, MPP_K_DBIRTH, MPP_K_DDEATH, MPP_K_GTRANS, MPP_K_DTRANS,
+       MPP_K_GTRANSF, MPP_K_DTRANSF };
+typedef struct {
+  double p_kernel[MPP_NKERNEL];
+  double sigma_trans;      /* 2   */
+  double sigma_transform;  /* 0.1 */
+  int32_t max_delta;       /* 8   */
+  int32_t _pad;
+} mpp_kernels;
+
+/* one fully specified proposal (tape replay); custom_types/perturbation.py:7-12 flattened */
+typedef struct {
+  int32_t kernel;
+  int32_t target;          /* slot removed / moved, -1 if none */
+  int32_t ax, ay;          /* proposed point */
+  double as, ar, aa;
+  double aux0, aux1;       /* raw normal deltas of the Gaussian kernels (Perturbation.data['delta']) */
+  int32_t param_id, new_class;
+  double u_accept;         /* the uniform of rjmcmc.py:113 */
+} mpp_proposal;
+
+/* per-step record; custom_types/rjmcmc.py:5-14 */
+typedef struct {
+  double dE, fwd, bwd, log_alpha, T;
+  int32_t accepted, n_after;
+} mpp_step_out;
+
+typedef struct mpp_ctx mpp_ctx;
+
+/* lifetime ------------------------------------------------------------------ */
+int mpp_create(int device_id, mpp_ctx **out);
+int mpp_destroy(mpp_ctx *ctx);
+const char *mpp_last_error(mpp_ctx *ctx);
+/* use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+int mpp_set_stream(mpp_ctx *ctx, void *hip_stream);
+int mpp_synchronize(mpp_ctx *ctx);
+/* "spec_waves": proposals evaluated speculatively per round (1 = strictly one at a time; results
+ * are identical for every value), "point_capacity": slots per tile, "cell_capacity" */
+int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);
+int64_t mpp_get_option(mpp_ctx *ctx, const char *name);
+
+/* score maps: ImageWMaps.detection_map / param_dist_maps (custom_types/image_w_maps.py:11-22).
+ * det: [n_tiles][H][W] float32; m0..m2: [n_tiles][H][W][32] float32 (size, ratio, angle). */
+int mpp_set_maps(mpp_ctx *ctx, int n_tiles, int H, int W, const float *det, const float *m0,
+                 const float *m1, const float *m2, int on_device);
+int mpp_set_model(mpp_ctx *ctx, const mpp_model *model, const mpp_mappings *mappings);
+/* make_kernels(image_data, intensity, rng): intensity[n_tiles] = max(1,len(init)) (sample_rjmcmc.py:68) */
+int mpp_set_kernels(mpp_ctx *ctx, const mpp_kernels *kernels, const double *intensity);
+
+/* EPointsSet (point_set/energy_point_set.py:18-166) ---------------------------- */
+int mpp_set_points(mpp_ctx *ctx, int tile, int n, const int32_t *xy, const double *marks);
+int mpp_get_points(mpp_ctx *ctx, int tile, int cap, int32_t *n, int32_t *xy, double *marks);
+int mpp_count(mpp_ctx *ctx, int tile, int32_t *n);
+/* total_energy(): combined energy and, optionally, [n][n_unit+n_pair] per-point vectors */
+int mpp_total_energy(mpp_ctx *ctx, int tile, double *energy, double *vectors_or_null);
+/* energy_delta(Perturbation) for a batch of perturbations with list removals/additions:
+ * case i removes slots rem[rem_off[i]..rem_off[i+1]) and adds rectangles add_off[i]..add_off[i+1] */
+int mpp_delta_batch(mpp_ctx *ctx, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                    const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE);
+/* papangelou(u, remove_u_from_point_set=True, return_energy_delta=True) of every point */
+int mpp_papangelou(mpp_ctx *ctx, int tile, double *dE);
+/* naive_detection (sample_rjmcmc.py:23-35): threshold + greedy distance-NMS, sets every tile's points */
+int mpp_naive_init(mpp_ctx *ctx, double threshold, double nms_distance);
+
+/* RJMCMC (rjmcmc_sampler/rjmcmc.py:52-187, sample_rjmcmc.py:38-102) ------------- */
+int mpp_set_schedule(mpp_ctx *ctx, double T0, double alpha, double T_target);
+/* replay n given proposals on one tile; out may be NULL */
+int mpp_replay(mpp_ctx *ctx, int tile, int n, const mpp_proposal *tape, mpp_step_out *out);
+/* n_steps of the chain on every tile at once; proposals from Philox4x32-10(key=seed,
+ * ctr=(step, block, chain = chain0+tile)).  trace_tile>=0 records that tile's steps. */
+int mpp_run(mpp_ctx *ctx, int64_t n_steps, uint64_t seed, uint32_t chain0, int trace_tile,
+            mpp_step_out *out_or_null, mpp_proposal *props_or_null);
+int mpp_step_index(mpp_ctx *ctx, int tile, int64_t *step);
+/* time of the last mpp_run / mpp_replay kernel in ms (HIP events on the ctx's stream) */
+int mpp_last_kernel_ms(mpp_ctx *ctx, double *ms);
+
+/* score-map epilogue of the two U-Nets (position_net/pos_net_model.py:186-200,338-346,
+ * torch_div.py:8-43; shape_net/shape_net_model.py:139-141): all device pointers.
+ * pos_out: [3][ldh][ldw] (vec0, vec1, mask logit; the network's padded output, of which the top-left
+ * H x W region is used) -> det [H][W];
+ * logits: [32][ldh][ldw] of one mark head -> marks [H][W][32], softmax over the 32 classes. */
+int mpp_posnet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *pos_out, double div_w,
+                        double div_b, float *det);
+int mpp_shapenet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *logits, float *marks);
+
+void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+int mpp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

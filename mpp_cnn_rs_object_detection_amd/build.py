@@ -1,0 +1,46 @@
+"""Build libmppgpu.so (hipcc, gfx950 only) in-tree."""
+from __future__ import annotations
+
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmppgpu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the CPU oracle forms no FMA, and parity of accept decisions is the contract
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def deps():
+    return sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(os.path.dirname(HERE), "include", "mpp_hip.h")]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps()):
+        return LIB
+    objs = []
+    for src in sources():
+        obj = os.path.splitext(src)[0] + ".o"
+        if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d)
+                                                   for d in [src] + deps()[len(sources()):]):
+            cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,579 @@
+// mpp_api.hip -- host side of the C ABI declared in include/mpp_hip.h.
+// Owns device memory, keeps the per-tile pointer table, launches the kernels of
+// mpp_sampler.hip / mpp_scratch.hip / mpp_maps.hip on the ctx's HIP stream.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mpp_device.hpp"
+
+extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec);
+extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int grid, size_t lds, const DevParams *P,
+                                       const TileRef *tiles, int tile0, long long n_steps, unsigned long long seed,
+                                       unsigned int chain0, const mpp_proposal *tape, int trace_tile,
+                                       mpp_step_out *out, mpp_proposal *props);
+extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
+                                          double *e_pts, double *vectors);
+extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
+                                       int n_cases, const int32_t *rem_off, const int32_t *rem,
+                                       const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
+                                       double *dE);
+extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
+                               double *scratch_rowtot);
+extern "C" void mpp_launch_naive_init(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles,
+                                      double threshold, double nms_dist, unsigned long long *cand, int cand_cap);
+extern "C" void mpp_launch_posnet_epilogue(hipStream_t st, const float *out, int H, int W, int ldh, int ldw, float w,
+                                           float b, float *det);
+extern "C" void mpp_launch_shapenet_epilogue(hipStream_t st, const float *logits, int H, int W, int ldh, int ldw,
+                                             float *marks);
+
+#define MPP_LDS_LIMIT (160 * 1024)
+
+struct mpp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr, own_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  DevParams hp;
+  DevParams *dp = nullptr;
+  bool params_dirty = true, tiles_dirty = true, have_model = false, have_kernels = false, have_maps = false;
+  int n_tiles = 0, H = 0, W = 0;
+  bool maps_borrowed = false;
+  float *det = nullptr, *m[3] = {nullptr, nullptr, nullptr};
+  double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr;
+  int cap = 1024, cell_cap = 32, spec = 1;
+  int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
+  double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
+  int64_t *step = nullptr;
+  std::vector<double> intensity;
+  std::vector<TileRef> h_tiles;
+  TileRef *d_tiles = nullptr;
+  double sched[3] = {1.0, 1.0, 0.0};
+  double last_ms = 0.0;
+};
+
+static int fail(mpp_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+#define HIPCHK(c, call)                                                                            \
+  do {                                                                                             \
+    hipError_t e_ = (call);                                                                        \
+    if (e_ != hipSuccess) return fail(c, -2, "%s failed: %s", #call, hipGetErrorString(e_));       \
+  } while (0)
+
+template <typename T>
+static hipError_t dalloc(T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  return hipMalloc((void **)p, count * sizeof(T));
+}
+
+static const char *chain_error_text(int e) {
+  switch (e) {
+    case 1: return "a 32-px cell of the spatial hash overflowed (raise option cell_capacity)";
+    case 2: return "point capacity of the tile exceeded (raise option point_capacity)";
+    case 3: return "proposal refers to a point that does not exist or lies outside the tile";
+    case 4: return "candidate list overflow (lower cell_capacity or report)";
+  }
+  return "unknown chain error";
+}
+
+extern "C" int mpp_abi_version(void) { return 1; }
+
+extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+extern "C" int mpp_create(int device_id, mpp_ctx **out) {
+  if (!out) return -1;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return -3;   // no GPU: fail loudly, no CPU fallback
+  if (device_id < 0 || device_id >= count) return -1;
+  mpp_ctx *c = new mpp_ctx();
+  c->device = device_id;
+  memset(&c->hp, 0, sizeof(DevParams));
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
+      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+      hipMalloc((void **)&c->dp, sizeof(DevParams)) != hipSuccess) {
+    delete c;
+    return -2;
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return 0;
+}
+
+static void free_tiles(mpp_ctx *c) {
+  if (!c->maps_borrowed) {
+    if (c->det) (void)hipFree(c->det);
+    for (int k = 0; k < 3; ++k) if (c->m[k]) (void)hipFree(c->m[k]);
+  }
+  c->det = nullptr; c->m[0] = c->m[1] = c->m[2] = nullptr;
+  void *ptrs[] = {c->rowpart, c->rowbase, c->rowtot, c->px, c->py, c->n, c->errd, c->ps, c->pr, c->pa, c->T, c->step,
+                  c->d_tiles};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  c->rowpart = c->rowbase = c->rowtot = nullptr; c->px = c->py = c->n = c->errd = nullptr;
+  c->ps = c->pr = c->pa = c->T = nullptr; c->step = nullptr; c->d_tiles = nullptr;
+}
+
+extern "C" int mpp_destroy(mpp_ctx *c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  free_tiles(c);
+  if (c->dp) (void)hipFree(c->dp);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return 0;
+}
+
+extern "C" const char *mpp_last_error(mpp_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+extern "C" int mpp_set_stream(mpp_ctx *c, void *s) {
+  if (!c) return -1;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return 0;
+}
+extern "C" int mpp_synchronize(mpp_ctx *c) {
+  if (!c) return -1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
+  if (!c || !name) return -1;
+  if (!strcmp(name, "spec_waves")) {
+    if (v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_waves must be 1, 2, 4, 8 or 16");
+    c->spec = (int)v;
+  } else if (!strcmp(name, "point_capacity")) {
+    if (c->have_maps) return fail(c, -1, "point_capacity must be set before mpp_set_maps");
+    if (v < 1 || v > 65535) return fail(c, -1, "point_capacity out of range");
+    c->cap = (int)v;
+  } else if (!strcmp(name, "cell_capacity")) {
+    if (v < 1 || v > 32) return fail(c, -1, "cell_capacity must be in 1..32");
+    c->cell_cap = (int)v; c->params_dirty = true;
+  } else return fail(c, -1, "unknown option %s", name);
+  return 0;
+}
+extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
+  if (!c || !name) return -1;
+  if (!strcmp(name, "spec_waves")) return c->spec;
+  if (!strcmp(name, "point_capacity")) return c->cap;
+  if (!strcmp(name, "cell_capacity")) return c->cell_cap;
+  if (!strcmp(name, "lds_bytes")) {
+    int ncell = c->hp.nx * c->hp.ny;
+    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, c->spec);
+  }
+  return -1;
+}
+
+static void refresh_grid(mpp_ctx *c) {
+  DevParams &P = c->hp;
+  double maxd = 0.0;
+  for (int p = 0; p < P.model.n_pair; ++p) if (P.model.pair[p].max_dist > maxd) maxd = P.model.pair[p].max_dist;
+  P.max_inter = P.model.n_pair > 0 ? maxd : 1.0;                  // energy_graph.py:26-29
+  P.res = maxd > 32.0 ? maxd : 32.0;                              // point_set.py:7,58
+  P.H = c->H; P.W = c->W;
+  P.nx = c->H > 0 ? (int)ceil((double)c->H / P.res) : 0;         // point_set.py:59-61
+  P.ny = c->W > 0 ? (int)ceil((double)c->W / P.res) : 0;
+  P.cap = c->cap; P.cell_cap = c->cell_cap; P.n_tiles = c->n_tiles;
+  c->params_dirty = true;
+}
+
+extern "C" int mpp_set_model(mpp_ctx *c, const mpp_model *model, const mpp_mappings *maps) {
+  if (!c || !model || !maps) return -1;
+  if (model->n_unit < 0 || model->n_unit > MPP_MAX_UNIT || model->n_pair < 0 || model->n_pair > MPP_MAX_PAIR)
+    return fail(c, -1, "bad term counts");
+  if (model->gate_term >= model->n_unit) return fail(c, -1, "gate_term must index a unit term");
+  for (int p = 0; p < model->n_pair; ++p) {
+    const mpp_pair_term &t = model->pair[p];
+    bool ok = (t.kind == MPP_P_OVERLAP && t.reduce == MPP_REDUCE_MAX) ||
+              (t.kind == MPP_P_ALIGN && ((t.p[0] != 0.0) == (t.reduce == MPP_REDUCE_MIN))) ||
+              ((t.kind == MPP_P_DIST_LE || t.kind == MPP_P_DIST_LT) && t.reduce == MPP_REDUCE_MAX);
+    if (!ok) return fail(c, -1, "pair term %d: unsupported (kind, reduce) combination", p);
+    if (!(t.max_dist > 0.0)) return fail(c, -1, "pair term %d: max_dist must be positive", p);
+  }
+  c->hp.model = *model;
+  c->hp.maps = *maps;
+  c->have_model = true;
+  refresh_grid(c);
+  return 0;
+}
+
+extern "C" int mpp_set_kernels(mpp_ctx *c, const mpp_kernels *k, const double *intensity) {
+  if (!c || !k) return -1;
+  double acc = 0.0;
+  for (int i = 0; i < MPP_NKERNEL; ++i) {
+    if (k->p_kernel[i] < 0) return fail(c, -1, "negative kernel probability");
+    acc += k->p_kernel[i]; c->hp.p_cum[i] = acc;
+  }
+  if (fabs(acc - 1.0) > 1e-8) return fail(c, -1, "kernel probabilities do not sum to 1");   // make_kernels.py:164-172
+  if (k->max_delta < 0 || k->max_delta > 15) return fail(c, -1, "max_delta must be in 0..15");
+  c->hp.kern = *k;
+  c->have_kernels = true;
+  c->params_dirty = true;
+  if (intensity) {
+    c->intensity.assign(intensity, intensity + (c->n_tiles > 0 ? c->n_tiles : 1));
+    c->tiles_dirty = true;
+  }
+  return 0;
+}
+
+extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *det, const float *m0, const float *m1,
+                            const float *m2, int on_device) {
+  if (!c) return -1;
+  if (n_tiles <= 0 || H <= 0 || W <= 0 || H > 65535 || W > 65535) return fail(c, -1, "bad tile geometry");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_tiles(c);
+  c->n_tiles = n_tiles; c->H = H; c->W = W;
+  const size_t hw = (size_t)H * W, T = (size_t)n_tiles;
+  const float *src[4] = {det, m0, m1, m2};
+  float **dst[4] = {&c->det, &c->m[0], &c->m[1], &c->m[2]};
+  c->maps_borrowed = on_device != 0;
+  for (int k = 0; k < 4; ++k) {
+    size_t cnt = T * hw * (k == 0 ? 1 : MPP_NCLASS);
+    if (on_device) {
+      if (!src[k]) return fail(c, -1, "borrowed device maps must all be given");
+      *dst[k] = const_cast<float *>(src[k]);
+    } else {
+      HIPCHK(c, dalloc(dst[k], cnt));
+      if (src[k]) HIPCHK(c, hipMemcpyAsync(*dst[k], src[k], cnt * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      else HIPCHK(c, hipMemsetAsync(*dst[k], 0, cnt * sizeof(float), c->stream));
+    }
+  }
+  HIPCHK(c, dalloc(&c->rowpart, T * hw));
+  HIPCHK(c, dalloc(&c->rowbase, T * (H + 1)));
+  HIPCHK(c, dalloc(&c->rowtot, T * H));
+  HIPCHK(c, dalloc(&c->px, T * c->cap)); HIPCHK(c, dalloc(&c->py, T * c->cap));
+  HIPCHK(c, dalloc(&c->ps, T * c->cap)); HIPCHK(c, dalloc(&c->pr, T * c->cap)); HIPCHK(c, dalloc(&c->pa, T * c->cap));
+  HIPCHK(c, dalloc(&c->n, T)); HIPCHK(c, dalloc(&c->errd, T)); HIPCHK(c, dalloc(&c->T, T * 3));
+  HIPCHK(c, dalloc(&c->step, T)); HIPCHK(c, dalloc(&c->d_tiles, T));
+  HIPCHK(c, hipMemsetAsync(c->n, 0, T * sizeof(int32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->errd, 0, T * sizeof(int32_t), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->step, 0, T * sizeof(int64_t), c->stream));
+  std::vector<double> sched(T * 3);
+  for (size_t t = 0; t < T; ++t) { sched[3 * t] = c->sched[0]; sched[3 * t + 1] = c->sched[1]; sched[3 * t + 2] = c->sched[2]; }
+  HIPCHK(c, hipMemcpyAsync(c->T, sched.data(), sched.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  for (size_t t = 0; t < T; ++t)
+    mpp_launch_cdf(c->stream, c->det + t * hw, H, W, c->rowpart + t * hw, c->rowbase + t * (H + 1), c->rowtot + t * H);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((int)c->intensity.size() != n_tiles) c->intensity.assign(n_tiles, 1.0);
+  c->have_maps = true;
+  c->tiles_dirty = true;
+  refresh_grid(c);
+  return 0;
+}
+
+static int push_state(mpp_ctx *c) {
+  if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
+  if (!c->have_model) return fail(c, -1, "mpp_set_model has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->tiles_dirty) {
+    const size_t hw = (size_t)c->H * c->W;
+    c->h_tiles.resize(c->n_tiles);
+    for (int t = 0; t < c->n_tiles; ++t) {
+      TileRef &r = c->h_tiles[t];
+      r.det = c->det + t * hw;
+      for (int k = 0; k < 3; ++k) r.m[k] = c->m[k] + t * hw * MPP_NCLASS;
+      r.rowpart = c->rowpart + t * hw; r.rowbase = c->rowbase + (size_t)t * (c->H + 1);
+      r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
+      r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
+      r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
+      r.intensity = c->intensity[t];
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_tiles, c->h_tiles.data(), sizeof(TileRef) * c->n_tiles, hipMemcpyHostToDevice,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tiles_dirty = false;
+  }
+  if (c->params_dirty) {
+    c->hp.cap = c->cap; c->hp.cell_cap = c->cell_cap; c->hp.n_tiles = c->n_tiles;
+    HIPCHK(c, hipMemcpyAsync(c->dp, &c->hp, sizeof(DevParams), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->params_dirty = false;
+  }
+  return 0;
+}
+static int check_tile(mpp_ctx *c, int tile) {
+  if (!c) return -1;
+  if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
+  if (tile < 0 || tile >= c->n_tiles) return fail(c, -1, "tile %d out of range", tile);
+  return 0;
+}
+
+extern "C" int mpp_set_points(mpp_ctx *c, int tile, int n, const int32_t *xy, const double *marks) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  if (n < 0 || n > c->cap) return fail(c, -4, "%d points exceed point_capacity %d", n, c->cap);
+  std::vector<int32_t> x(n), y(n);
+  std::vector<double> s(n), r(n), a(n);
+  for (int i = 0; i < n; ++i) {
+    x[i] = xy[2 * i]; y[i] = xy[2 * i + 1];
+    if (x[i] < 0 || x[i] >= c->H || y[i] < 0 || y[i] >= c->W)
+      return fail(c, -5, "point %d (%d,%d) is outside the %dx%d tile", i, x[i], y[i], c->H, c->W);  // point_set.py:99
+    s[i] = marks[3 * i]; r[i] = marks[3 * i + 1]; a[i] = marks[3 * i + 2];
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t o = (size_t)tile * c->cap;
+  HIPCHK(c, hipMemcpyAsync(c->px + o, x.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->py + o, y.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->ps + o, s.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->pr + o, r.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->pa + o, a.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int32_t nn = n, zero = 0;
+  HIPCHK(c, hipMemcpyAsync(c->n + tile, &nn, sizeof nn, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->errd + tile, &zero, sizeof zero, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int mpp_count(mpp_ctx *c, int tile, int32_t *n) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(n, c->n + tile, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" int mpp_get_points(mpp_ctx *c, int tile, int cap, int32_t *n_out, int32_t *xy, double *marks) {
+  int32_t n = 0;
+  int rc = mpp_count(c, tile, &n);
+  if (rc) return rc;
+  if (n_out) *n_out = n;
+  int m = n < cap ? n : cap;
+  if (m <= 0 || !xy || !marks) return 0;
+  std::vector<int32_t> x(m), y(m);
+  std::vector<double> s(m), r(m), a(m);
+  size_t o = (size_t)tile * c->cap;
+  HIPCHK(c, hipMemcpyAsync(x.data(), c->px + o, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(y.data(), c->py + o, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(s.data(), c->ps + o, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(r.data(), c->pr + o, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(a.data(), c->pa + o, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < m; ++i) {
+    xy[2 * i] = x[i]; xy[2 * i + 1] = y[i];
+    marks[3 * i] = s[i]; marks[3 * i + 1] = r[i]; marks[3 * i + 2] = a[i];
+  }
+  return 0;
+}
+
+extern "C" int mpp_total_energy(mpp_ctx *c, int tile, double *energy, double *vectors) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  if ((rc = push_state(c))) return rc;
+  int32_t n = 0;
+  if ((rc = mpp_count(c, tile, &n))) return rc;
+  double e = 0.0;
+  if (n > 0) {
+    int nt = c->hp.model.n_unit + c->hp.model.n_pair;
+    double *d_e = nullptr, *d_v = nullptr;
+    HIPCHK(c, dalloc(&d_e, (size_t)n));
+    if (vectors) HIPCHK(c, dalloc(&d_v, (size_t)n * nt));
+    mpp_launch_point_energies(c->stream, c->dp, c->d_tiles, tile, n, d_e, d_v);
+    std::vector<double> he(n);
+    hipError_t e1 = hipMemcpyAsync(he.data(), d_e, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipSuccess;
+    if (vectors) e2 = hipMemcpyAsync(vectors, d_v, (size_t)n * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    hipError_t e3 = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_e);
+    if (d_v) (void)hipFree(d_v);
+    HIPCHK(c, e1); HIPCHK(c, e2); HIPCHK(c, e3);
+    for (int i = 0; i < n; ++i) e += he[i];                      // same order as the reference's np.sum over points
+  }
+  if (energy) *energy = e;
+  return 0;
+}
+
+extern "C" int mpp_delta_batch(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                               const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  if ((rc = push_state(c))) return rc;
+  if (n_cases <= 0) return 0;
+  int32_t n = 0;
+  if ((rc = mpp_count(c, tile, &n))) return rc;
+  const int n_rem = rem_off[n_cases], n_add = add_off[n_cases];
+  for (int i = 0; i < n_rem; ++i)
+    if (rem[i] < 0 || rem[i] >= n) return fail(c, -6, "removal of slot %d: no such point (n=%d)", rem[i], n);  // KeyError
+  for (int i = 0; i < n_add; ++i)
+    if (add_xy[2 * i] < 0 || add_xy[2 * i] >= c->H || add_xy[2 * i + 1] < 0 || add_xy[2 * i + 1] >= c->W)
+      return fail(c, -5, "added point %d is outside the tile", i);
+  int32_t *d_ro = nullptr, *d_r = nullptr, *d_ao = nullptr, *d_axy = nullptr;
+  double *d_am = nullptr, *d_out = nullptr;
+  HIPCHK(c, dalloc(&d_ro, (size_t)n_cases + 1)); HIPCHK(c, dalloc(&d_ao, (size_t)n_cases + 1));
+  HIPCHK(c, dalloc(&d_r, (size_t)n_rem)); HIPCHK(c, dalloc(&d_axy, (size_t)2 * n_add));
+  HIPCHK(c, dalloc(&d_am, (size_t)3 * n_add)); HIPCHK(c, dalloc(&d_out, (size_t)n_cases));
+  hipError_t e = hipSuccess;
+  auto up = [&](void *dst, const void *src, size_t bytes) {
+    if (bytes && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+  };
+  up(d_ro, rem_off, (n_cases + 1) * sizeof(int32_t)); up(d_ao, add_off, (n_cases + 1) * sizeof(int32_t));
+  up(d_r, rem, n_rem * sizeof(int32_t)); up(d_axy, add_xy, 2 * (size_t)n_add * sizeof(int32_t));
+  up(d_am, add_marks, 3 * (size_t)n_add * sizeof(double));
+  if (e == hipSuccess) {
+    mpp_launch_delta_batch(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, d_out);
+    e = hipMemcpyAsync(dE, d_out, n_cases * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  }
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  void *ptrs[] = {d_ro, d_r, d_ao, d_axy, d_am, d_out};
+  for (void *p : ptrs) (void)hipFree(p);
+  HIPCHK(c, e); HIPCHK(c, e2);
+  return 0;
+}
+
+extern "C" int mpp_papangelou(mpp_ctx *c, int tile, double *dE) {
+  int32_t n = 0;
+  int rc = mpp_count(c, tile, &n);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  std::vector<int32_t> ro(n + 1), r(n), ao(n + 1, 0);
+  for (int i = 0; i <= n; ++i) ro[i] = i;
+  for (int i = 0; i < n; ++i) r[i] = i;
+  int32_t dummy_xy[2] = {0, 0};
+  double dummy_m[3] = {0, 0, 0};
+  rc = mpp_delta_batch(c, tile, n, ro.data(), r.data(), ao.data(), dummy_xy, dummy_m, dE);
+  if (rc) return rc;
+  for (int i = 0; i < n; ++i) dE[i] = -dE[i];     // E(with u) - E(without u), energy_point_set.py:108-110
+  return 0;
+}
+
+extern "C" int mpp_naive_init(mpp_ctx *c, double threshold, double nms_distance) {
+  if (!c) return -1;
+  int rc = push_state(c);
+  if (rc) return rc;
+  const int cand_cap = c->H * c->W;
+  unsigned long long *cand = nullptr;
+  HIPCHK(c, dalloc(&cand, (size_t)c->n_tiles * cand_cap));
+  mpp_launch_naive_init(c->stream, c->dp, c->d_tiles, c->n_tiles, threshold, nms_distance, cand, cand_cap);
+  hipError_t e = hipGetLastError(), e2 = hipStreamSynchronize(c->stream);
+  (void)hipFree(cand);
+  HIPCHK(c, e); HIPCHK(c, e2);
+  std::vector<int32_t> herr(c->n_tiles);
+  HIPCHK(c, hipMemcpy(herr.data(), c->errd, c->n_tiles * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int t = 0; t < c->n_tiles; ++t)
+    if (herr[t]) return fail(c, -10 - herr[t], "naive init, tile %d: %s", t, chain_error_text(herr[t]));
+  return 0;
+}
+
+extern "C" int mpp_set_schedule(mpp_ctx *c, double T0, double alpha, double T_target) {
+  if (!c) return -1;
+  if (!(T0 >= T_target)) return fail(c, -1, "t0 must be >= t_target");          // rjmcmc.py:71
+  c->sched[0] = T0; c->sched[1] = alpha; c->sched[2] = T_target;
+  if (c->have_maps) {
+    std::vector<double> sched((size_t)c->n_tiles * 3);
+    for (int t = 0; t < c->n_tiles; ++t) { sched[3 * t] = T0; sched[3 * t + 1] = alpha; sched[3 * t + 2] = T_target; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->T, sched.data(), sched.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->step, 0, c->n_tiles * sizeof(int64_t), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t seed, uint32_t chain0,
+                     const mpp_proposal *d_tape, int trace_tile, mpp_step_out *d_out, mpp_proposal *d_props) {
+  int rc = push_state(c);
+  if (rc) return rc;
+  if (!d_tape && !c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
+  const int ncell = c->hp.nx * c->hp.ny;
+  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, c->spec);
+  if (lds > MPP_LDS_LIMIT)
+    return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
+                lds, MPP_LDS_LIMIT);
+  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
+                             d_tape, trace_tile, d_out, d_props));
+  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+  HIPCHK(c, hipEventSynchronize(c->ev1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->last_ms = ms;
+  std::vector<int32_t> herr(grid);
+  HIPCHK(c, hipMemcpy(herr.data(), c->errd + tile0, grid * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int t = 0; t < grid; ++t)
+    if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
+  return 0;
+}
+
+extern "C" int mpp_replay(mpp_ctx *c, int tile, int n, const mpp_proposal *tape, mpp_step_out *out) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  if (n <= 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  mpp_proposal *d_tape = nullptr;
+  mpp_step_out *d_out = nullptr;
+  HIPCHK(c, dalloc(&d_tape, (size_t)n));
+  if (out) HIPCHK(c, dalloc(&d_out, (size_t)n));
+  hipError_t e = hipMemcpyAsync(d_tape, tape, (size_t)n * sizeof(mpp_proposal), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) rc = run_chain(c, 1, tile, n, 0, 0, d_tape, tile, d_out, nullptr);
+  if (e == hipSuccess && out)
+    e = hipMemcpy(out, d_out, (size_t)n * sizeof(mpp_step_out), hipMemcpyDeviceToHost);
+  (void)hipFree(d_tape);
+  if (d_out) (void)hipFree(d_out);
+  HIPCHK(c, e);
+  return rc;
+}
+
+extern "C" int mpp_run(mpp_ctx *c, int64_t n_steps, uint64_t seed, uint32_t chain0, int trace_tile, mpp_step_out *out,
+                       mpp_proposal *props) {
+  if (!c) return -1;
+  if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
+  if (n_steps <= 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  mpp_step_out *d_out = nullptr;
+  mpp_proposal *d_props = nullptr;
+  bool tr = trace_tile >= 0 && trace_tile < c->n_tiles;
+  if (tr && out) HIPCHK(c, dalloc(&d_out, (size_t)n_steps));
+  if (tr && props) HIPCHK(c, dalloc(&d_props, (size_t)n_steps));
+  int rc = run_chain(c, c->n_tiles, 0, n_steps, seed, chain0, nullptr, tr ? trace_tile : -1, d_out, d_props);
+  hipError_t e = hipSuccess;
+  if (d_out) e = hipMemcpy(out, d_out, (size_t)n_steps * sizeof(mpp_step_out), hipMemcpyDeviceToHost);
+  if (d_props && e == hipSuccess) e = hipMemcpy(props, d_props, (size_t)n_steps * sizeof(mpp_proposal), hipMemcpyDeviceToHost);
+  if (d_out) (void)hipFree(d_out);
+  if (d_props) (void)hipFree(d_props);
+  HIPCHK(c, e);
+  return rc;
+}
+
+extern "C" int mpp_step_index(mpp_ctx *c, int tile, int64_t *step) {
+  int rc = check_tile(c, tile);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpy(step, c->step + tile, sizeof(int64_t), hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int mpp_last_kernel_ms(mpp_ctx *c, double *ms) {
+  if (!c || !ms) return -1;
+  *ms = c->last_ms;
+  return 0;
+}
+
+extern "C" int mpp_posnet_epilogue(mpp_ctx *c, int H, int W, int ldh, int ldw, const float *pos_out, double div_w,
+                                   double div_b, float *det) {
+  if (!c || !pos_out || !det || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  mpp_launch_posnet_epilogue(c->stream, pos_out, H, W, ldh, ldw, (float)div_w, (float)div_b, det);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+extern "C" int mpp_shapenet_epilogue(mpp_ctx *c, int H, int W, int ldh, int ldw, const float *logits, float *marks) {
+  if (!c || !logits || !marks || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  mpp_launch_shapenet_epilogue(c->stream, logits, H, W, ldh, ldw, marks);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}

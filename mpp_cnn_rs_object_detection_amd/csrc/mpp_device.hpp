@@ -1,0 +1,270 @@
+// mpp_device.hpp -- device-side data model shared by the sampler and the from-scratch
+// energy kernels (gfx950 / wave64 only).
+//
+// Arithmetic policy: score maps are float32 in HBM; every energy, density and
+// acceptance quantity is computed in float64 from those reads (the reference works
+// in NumPy float64 on float32 maps).  The library is compiled with
+// -ffp-contract=off so that no FMA is formed that the CPU oracle does not form.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mpp_hip.h"
+
+#define WAVE 64
+#define MPP_PI 3.14159265358979323846
+#define MPP_TWO_PI 6.283185307179586476925286766559
+#define EPS_GREEN 1e-16       // rjmcmc.py:15
+#define AREA_EPS 1e-6         // prior_energies.py:18
+#define DEGENERATE_AREA 1e-12 // a zero-width rectangle is a segment: intersection area 0
+
+// everything a chain needs that is the same for all tiles of a ctx (lives in HBM, read
+// through scalar loads: it is wave-uniform)
+struct DevParams {
+  mpp_model model;
+  mpp_mappings maps;
+  mpp_kernels kern;
+  double p_cum[MPP_NKERNEL];
+  double max_inter;     // largest pair max_dist (energy_graph.py:26-29)
+  double res;           // cell size = max(max_inter, 32) (point_set.py:58)
+  int32_t H, W, nx, ny; // grid dims (point_set.py:59-61)
+  int32_t cap, cell_cap, n_tiles, _pad;
+};
+
+// per-tile device pointers
+struct TileRef {
+  const float *det;
+  const float *m[3];
+  const double *rowpart;   // [H][W] inclusive partial sums of det within each row
+  const double *rowbase;   // [H+1] exclusive prefix of row totals; rowbase[H] = sum(det)
+  // point configuration, dense slots (capacity cap)
+  int32_t *px, *py;
+  double *ps, *pr, *pa;
+  int32_t *n;
+  double *T;               // current temperature
+  int64_t *step;           // steps done so far
+  int32_t *err;            // sticky error code of the chain
+  double intensity;
+};
+
+struct Rect {
+  int x, y;
+  double s, r, a;
+};
+
+// derived geometry of a rectangle (base/shapes/rectangle.py:20-31,69-100):
+// length = 2*size/(1+ratio), width = ratio*length, corners = R(angle+pi/2)*(+-length/2,+-width/2)+centre
+struct Geo {
+  int x, y;
+  double hl, hw, ca, sa;
+};
+
+__device__ __forceinline__ Geo make_geo(const Rect &q) {
+  Geo g;
+  g.x = q.x; g.y = q.y;
+  double length = (2.0 * q.s) / (1.0 + q.r);
+  double width = q.r * length;
+  g.hl = length / 2.0; g.hw = width / 2.0;
+  double al = q.a + MPP_PI / 2.0;
+  g.ca = cos(al); g.sa = sin(al);
+  return g;
+}
+__device__ __forceinline__ double geo_area(const Geo &g) { return (2.0 * g.hl) * (2.0 * g.hw); }
+
+__device__ __forceinline__ void geo_corners(const Geo &g, double *px, double *py) {
+  // counter-clockwise: (+,+) (-,+) (-,-) (+,-)
+  const double sx[4] = {1, -1, -1, 1}, sy[4] = {1, 1, -1, -1};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double vx = sx[i] * g.hl, vy = sy[i] * g.hw;
+    px[i] = g.ca * vx - g.sa * vy + (double)g.x;
+    py[i] = g.sa * vx + g.ca * vy + (double)g.y;
+  }
+}
+
+// Sutherland-Hodgman: area of (convex quad S) clipped by (convex ccw quad C)
+__device__ inline double clip_area(const double *sx, const double *sy, const double *cx, const double *cy) {
+  double ax[8], ay[8], bx[8], by[8];
+  int na = 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ax[i] = sx[i]; ay[i] = sy[i]; }
+  for (int e = 0; e < 4 && na > 0; ++e) {
+    double x0 = cx[e], y0 = cy[e], x1 = cx[(e + 1) & 3], y1 = cy[(e + 1) & 3];
+    double ex = x1 - x0, ey = y1 - y0;
+    int nb = 0;
+    double px = ax[na - 1], py = ay[na - 1];
+    double sp = ex * (py - y0) - ey * (px - x0);
+    for (int i = 0; i < na; ++i) {
+      double qx = ax[i], qy = ay[i];
+      double sq = ex * (qy - y0) - ey * (qx - x0);
+      if (sq >= 0) {
+        if (sp < 0 && nb < 8) {
+          double t = sp / (sp - sq);
+          bx[nb] = px + t * (qx - px); by[nb] = py + t * (qy - py); ++nb;
+        }
+        if (nb < 8) { bx[nb] = qx; by[nb] = qy; ++nb; }
+      } else if (sp >= 0 && nb < 8) {
+        double t = sp / (sp - sq);
+        bx[nb] = px + t * (qx - px); by[nb] = py + t * (qy - py); ++nb;
+      }
+      px = qx; py = qy; sp = sq;
+    }
+    for (int i = 0; i < nb; ++i) { ax[i] = bx[i]; ay[i] = by[i]; }
+    na = nb;
+  }
+  if (na < 3) return 0.0;
+  double s = 0.0;
+  for (int i = 0; i < na; ++i) {
+    int j = (i + 1 == na) ? 0 : i + 1;
+    s += ax[i] * ay[j] - ax[j] * ay[i];
+  }
+  return 0.5 * fabs(s);
+}
+
+// a strict total order on rectangles; the pair energy always clips the smaller against the
+// larger, which makes it a function of the unordered pair (the reference shares one PairEnergy
+// object between both endpoints, energy_graph.py:74-77)
+__device__ __forceinline__ bool rect_less(int ax, int ay, double as, double ar, double aa, int bx, int by, double bs,
+                                          double br, double ba) {
+  if (ax != bx) return ax < bx;
+  if (ay != by) return ay < by;
+  if (as != bs) return as < bs;
+  if (ar != br) return ar < br;
+  return aa < ba;
+}
+
+// RectangleOverlapEnergy (prior_energies.py:11-24); `first` tells whether u is the subject
+__device__ inline double overlap_energy(const Geo &u, const Geo &v, bool u_first) {
+  double A = geo_area(u), B = geo_area(v);
+  double mn = A < B ? A : B;
+  if (mn < DEGENERATE_AREA) return 0.0;
+  double dx = (double)(u.x - v.x), dy = (double)(u.y - v.y);
+  double ru = sqrt(u.hl * u.hl + u.hw * u.hw), rv = sqrt(v.hl * v.hl + v.hw * v.hw);
+  double reach = ru + rv;
+  if (dx * dx + dy * dy > reach * reach * 1.0000001) return 0.0;   // circumscribed circles apart
+  double ax[4], ay[4], bx[4], by[4];
+  if (u_first) { geo_corners(u, ax, ay); geo_corners(v, bx, by); }
+  else { geo_corners(v, ax, ay); geo_corners(u, bx, by); }
+  return clip_area(ax, ay, bx, by) / (mn + AREA_EPS);
+}
+
+__device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// mappings.py:44-62: class = max{i : v >= edge_i}
+__device__ __forceinline__ int value_to_class(const DevParams *P, int k, double v) {
+  int lo = 0, hi = MPP_NCLASS;       // invariant: edges[lo] <= v (or lo == 0), edges[hi] > v
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (v >= P->maps.edges[k][mid]) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__device__ __forceinline__ double mark_of(const Rect &q, int k) { return k == 0 ? q.s : (k == 1 ? q.r : q.a); }
+__device__ __forceinline__ void set_mark(Rect &q, int k, double v) {
+  if (k == 0) q.s = v; else if (k == 1) q.r = v; else q.a = v;
+}
+__device__ __forceinline__ const float *mark_row(const DevParams *P, const TileRef &t, int k, int x, int y) {
+  return t.m[k] + ((size_t)x * P->W + y) * MPP_NCLASS;
+}
+
+// one unit energy term of a rectangle
+__device__ inline double unit_value(const DevParams *P, const TileRef &t, const mpp_unit_term &u, const Rect &q,
+                                    const Geo &g) {
+  switch (u.kind) {
+    case MPP_U_POSITION: {
+      float e = -2.0f * (t.det[(size_t)q.x * P->W + q.y] - (float)u.p[0]);   // float32, as numpy does
+      return (double)e;
+    }
+    case MPP_U_SHAPE_REMAP: {
+      double acc = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
+        acc += -2.0 * sigmoid_d(p * u.p[k] + u.p[3 + k]) + 1.0;
+      }
+      return acc / 3.0;
+    }
+    case MPP_U_MARK_NEG: {
+      int k = (int)u.p[0];
+      return -(double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
+    }
+    case MPP_U_MARK_REMAP: {
+      int k = (int)u.p[0];
+      double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
+      return -2.0 * sigmoid_d(p * u.p[1] + u.p[2]) + 1.0;
+    }
+    case MPP_U_AREA: {
+      double A = geo_area(g), lo = u.p[0] - A, hi = A - u.p[1];
+      double m = lo > hi ? lo : hi;
+      return m > 0.0 ? m : 0.0;
+    }
+    case MPP_U_RATIO_PRIOR: return fabs(u.p[0] - q.r);
+    case MPP_U_CONST: return u.p[0];
+  }
+  return 0.0;
+}
+
+// the part of a point's combined energy that does not depend on its neighbours:
+// lin = lin0 + sum_units coef*g*v ; gate = [v_gate <= thr]
+__device__ inline void unit_part(const DevParams *P, const TileRef &t, const Rect &q, const Geo &g, double *lin,
+                                 int *gate, double *vec_or_null) {
+  const mpp_model &M = P->model;
+  double v[MPP_MAX_UNIT];
+  for (int k = 0; k < M.n_unit; ++k) {
+    v[k] = unit_value(P, t, M.unit[k], q, g);
+    if (vec_or_null) vec_or_null[k] = v[k];
+  }
+  int gt = 1;
+  if (M.gate_term >= 0) gt = (v[M.gate_term] <= M.gate_thr) ? 1 : 0;
+  double l = M.lin0;
+  for (int k = 0; k < M.n_unit; ++k) l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v[k];
+  *lin = l; *gate = gt;
+}
+__device__ __forceinline__ double pair_part(const DevParams *P, int gate, double r0, double r1) {
+  const mpp_model &M = P->model;
+  double l = 0.0;
+  if (M.n_pair > 0) l += M.pair[0].coef * (M.pair[0].gated ? (double)gate : 1.0) * r0;
+  if (M.n_pair > 1) l += M.pair[1].coef * (M.pair[1].gated ? (double)gate : 1.0) * r1;
+  return l;
+}
+__device__ __forceinline__ double finish_energy(const DevParams *P, double lin) {
+  return P->model.combinator == MPP_C_LOGISTIC ? 2.0 * sigmoid_d(lin) - 1.0 : lin;
+}
+__device__ __forceinline__ double reduce2(int mode, double a, double b) {
+  return mode == MPP_REDUCE_MAX ? (a > b ? a : b) : (a < b ? a : b);
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+__device__ __forceinline__ double wave_reduce(int mode, double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = reduce2(mode, v, __shfl_xor(v, o, WAVE));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+  return v;
+}
+
+// ---- Philox4x32-10 --------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+  return (double)((((uint64_t)(a >> 5)) << 26) | (uint64_t)(b >> 6)) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double u32d(uint32_t a) { return (double)a * (1.0 / 4294967296.0); }
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t n) { return (uint32_t)(((uint64_t)a * n) >> 32); }

@@ -1,0 +1,158 @@
+// mpp_maps.hip -- per-tile map preparation and the score-map epilogues of the two U-Nets.
+//
+//  * birth CDF tables for the data-driven birth kernel (replaces the O(H*W) cumsum the reference
+//    redoes on every proposal, utils/sampler2d.py:43);
+//  * naive_detection (sample_rjmcmc.py:23-35 + utils/nms.py:68-110) as one workgroup per tile;
+//  * PosNet epilogue: sigmoid(mask) , divergence of the vector field, 1x1 "div_clf" conv, sigmoid
+//    (pos_net_model.py:186-200, :338-346; torch_div.py:8-43), fused, one read of 3 ch, one write;
+//  * ShapeNet epilogue: softmax over 32 classes + CHW -> HWC transpose through LDS so that both
+//    the read (64 consecutive pixels of one channel) and the write (64 pixels x 32 classes = 8 KiB
+//    contiguous) are fully coalesced (shape_net_model.py:139-141 + data_loaders.py:54).
+#include "mpp_device.hpp"
+
+// ---- birth CDF ---------------------------------------------------------------------------------
+__global__ void k_row_partial(const float *det, int H, int W, double *rowpart, double *rowtot) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= H) return;
+  double s = 0.0;
+  for (int j = 0; j < W; ++j) { s += (double)det[(size_t)r * W + j]; rowpart[(size_t)r * W + j] = s; }
+  rowtot[r] = s;
+}
+__global__ void k_row_base(const double *rowtot, int H, double *rowbase) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int r = 0; r < H; ++r) { rowbase[r] = s; s += rowtot[r]; }
+    rowbase[H] = s;
+  }
+}
+extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
+                               double *scratch_rowtot) {
+  hipLaunchKernelGGL(k_row_partial, dim3((H + 63) / 64), dim3(64), 0, st, det, H, W, rowpart, scratch_rowtot);
+  hipLaunchKernelGGL(k_row_base, dim3(1), dim3(64), 0, st, scratch_rowtot, H, rowbase);
+}
+
+// ---- naive detection ------------------------------------------------------------------------------
+// keys: (float bits << 32) | flat index ; det >= 0 so the bit pattern orders like the value; ties go to
+// the larger index (the convention of the CPU oracle)
+__global__ __launch_bounds__(256) void k_naive_init(const DevParams *P, const TileRef *tiles, double threshold,
+                                                    double nms_dist, unsigned long long *cand_all, int cand_cap) {
+  __shared__ unsigned long long best[256];
+  __shared__ int s_count;
+  TileRef t = tiles[blockIdx.x];
+  unsigned long long *cand = cand_all + (size_t)blockIdx.x * cand_cap;
+  const int hw = P->H * P->W;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+    float v = t.det[i];
+    if ((double)v >= threshold) {
+      int k = atomicAdd(&s_count, 1);
+      if (k < cand_cap) cand[k] = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
+    }
+  }
+  __syncthreads();
+  int nc = min(s_count, cand_cap);
+  int n_out = 0, err = s_count > cand_cap ? 2 : 0;
+  while (true) {
+    unsigned long long m = 0;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) m = max(m, cand[i]);
+    best[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if ((int)threadIdx.x < s) best[threadIdx.x] = max(best[threadIdx.x], best[threadIdx.x + s]);
+      __syncthreads();
+    }
+    unsigned long long b = best[0];
+    __syncthreads();
+    if (b == 0) break;
+    int idx = (int)(b & 0xffffffffu), bx = idx / P->W, by = idx % P->W;
+    if (n_out < P->cap) {
+      if (threadIdx.x < 3) {
+        int k = threadIdx.x;
+        const float *row = mark_row(P, t, k, bx, by);
+        int am = 0;
+        for (int i = 1; i < MPP_NCLASS; ++i) if (row[i] > row[am]) am = i;
+        double v = P->maps.edges[k][am];
+        if (k == 0) t.ps[n_out] = v; else if (k == 1) t.pr[n_out] = v; else t.pa[n_out] = v;
+      }
+      if (threadIdx.x == 3) { t.px[n_out] = bx; t.py[n_out] = by; }
+    } else err = 2;
+    ++n_out;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+      unsigned long long c = cand[i];
+      if (c == 0) continue;
+      int ci = (int)(c & 0xffffffffu);
+      double dx = (double)(ci / P->W - bx), dy = (double)(ci % P->W - by);
+      if (!(sqrt(dx * dx + dy * dy) > nms_dist)) cand[i] = 0;   // utils/nms.py:103-105 keeps only d > threshold
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { *t.n = min(n_out, P->cap); if (err) *t.err = err; }
+}
+extern "C" void mpp_launch_naive_init(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles,
+                                      double threshold, double nms_dist, unsigned long long *cand, int cand_cap) {
+  hipLaunchKernelGGL(k_naive_init, dim3(n_tiles), dim3(256), 0, st, P, tiles, threshold, nms_dist, cand, cand_cap);
+}
+
+// ---- PosNet epilogue --------------------------------------------------------------------------------
+// out: [3][Hp][ldw] float32 (vec0 = d/d row component, vec1 = d/d col component, mask logit);
+// det[x][y] = sigmoid(w * (d vec0/dx + d vec1/dy) * sigmoid(mask) + b), central differences inside,
+// one-sided at the borders of the H x W region (torch.gradient semantics).
+__global__ __launch_bounds__(256) void k_posnet_epilogue(const float *out, int H, int W, int ldh, int ldw, float w,
+                                                         float b, float *det) {
+  int y = blockIdx.x * blockDim.x + threadIdx.x, x = blockIdx.y;
+  if (y >= W || x >= H) return;
+  const size_t plane = (size_t)ldh * ldw;
+  const float *v0 = out, *v1 = out + plane, *mk = out + 2 * plane;
+  float g0, g1;
+  if (H == 1) g0 = 0.f;
+  else if (x == 0) g0 = v0[(size_t)1 * ldw + y] - v0[y];
+  else if (x == H - 1) g0 = v0[(size_t)x * ldw + y] - v0[(size_t)(x - 1) * ldw + y];
+  else g0 = (v0[(size_t)(x + 1) * ldw + y] - v0[(size_t)(x - 1) * ldw + y]) / 2.0f;
+  if (W == 1) g1 = 0.f;
+  else if (y == 0) g1 = v1[(size_t)x * ldw + 1] - v1[(size_t)x * ldw];
+  else if (y == W - 1) g1 = v1[(size_t)x * ldw + y] - v1[(size_t)x * ldw + y - 1];
+  else g1 = (v1[(size_t)x * ldw + y + 1] - v1[(size_t)x * ldw + y - 1]) / 2.0f;
+  float mask = 1.0f / (1.0f + expf(-mk[(size_t)x * ldw + y]));
+  float score = w * ((g0 + g1) * mask) + b;
+  det[(size_t)x * W + y] = 1.0f / (1.0f + expf(-score));
+}
+extern "C" void mpp_launch_posnet_epilogue(hipStream_t st, const float *out, int H, int W, int ldh, int ldw, float w,
+                                           float b, float *det) {
+  hipLaunchKernelGGL(k_posnet_epilogue, dim3((W + 255) / 256, H), dim3(256), 0, st, out, H, W, ldh, ldw, w, b, det);
+}
+
+// ---- ShapeNet epilogue --------------------------------------------------------------------------------
+// logits: [32][ldh][ldw] -> marks [H][W][32] = softmax over classes.  One block = 64 pixels of a row.
+__global__ __launch_bounds__(256) void k_shapenet_epilogue(const float *logits, int H, int W, int ldh, int ldw,
+                                                           float *marks) {
+  __shared__ float tile[MPP_NCLASS][WAVE + 1];
+  const int x = blockIdx.y, y0 = blockIdx.x * WAVE;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;      // 4 waves, each reads 8 channels
+  const size_t plane = (size_t)ldh * ldw;
+  for (int ch = grp; ch < MPP_NCLASS; ch += 4) {
+    int y = y0 + lane;
+    tile[ch][lane] = y < W ? logits[ch * plane + (size_t)x * ldw + y] : 0.f;
+  }
+  __syncthreads();
+  // pixel p = threadIdx.x / 4 handles 8 classes: threads of one pixel sit in one wave -> shuffles
+  const int p = threadIdx.x >> 2, q = threadIdx.x & 3;
+  float v[8], m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = tile[q * 8 + i][p]; m = fmaxf(m, v[i]); }
+  m = fmaxf(m, __shfl_xor(m, 1, WAVE)); m = fmaxf(m, __shfl_xor(m, 2, WAVE));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+  s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
+  if (y0 + p < W) {
+    float4 *dst = (float4 *)(marks + ((size_t)x * W + y0 + p) * MPP_NCLASS + q * 8);
+    dst[0] = make_float4(v[0] / s, v[1] / s, v[2] / s, v[3] / s);
+    dst[1] = make_float4(v[4] / s, v[5] / s, v[6] / s, v[7] / s);
+  }
+}
+extern "C" void mpp_launch_shapenet_epilogue(hipStream_t st, const float *logits, int H, int W, int ldh, int ldw,
+                                             float *marks) {
+  hipLaunchKernelGGL(k_shapenet_epilogue, dim3((W + WAVE - 1) / WAVE, H), dim3(256), 0, st, logits, H, W, ldh, ldw,
+                     marks);
+}

@@ -1,0 +1,361 @@
+"""ctypes binding of ``libmppgpu.so`` (C ABI: ``include/mpp_hip.h``).
+
+This is the only door between the Python host code and the HIP kernels.  There
+is no CPU fallback: if the library is missing or no GPU is visible, importing
+the symbols or creating a context raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .energies import ModelDesc
+from .kernels import KernelDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmppgpu.so")
+
+MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 8
+
+#: every symbol include/mpp_hip.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
+    "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
+    "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
+    "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
+    "mpp_shapenet_epilogue", "mpp_philox4x32", "mpp_abi_version",
+]
+
+
+class UnitTermC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("gated", C.c_int32), ("coef", C.c_double), ("p", C.c_double * 8)]
+
+
+class PairTermC(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("gated", C.c_int32), ("reduce", C.c_int32), ("_pad", C.c_int32),
+                ("coef", C.c_double), ("max_dist", C.c_double), ("p", C.c_double * 2)]
+
+
+class ModelC(C.Structure):
+    _fields_ = [("n_unit", C.c_int32), ("n_pair", C.c_int32), ("combinator", C.c_int32), ("gate_term", C.c_int32),
+                ("gate_thr", C.c_double), ("lin0", C.c_double),
+                ("unit", UnitTermC * MAX_UNIT), ("pair", PairTermC * MAX_PAIR)]
+
+
+class MappingsC(C.Structure):
+    _fields_ = [("cyclic", C.c_int32 * 3), ("_pad", C.c_int32), ("vmin", C.c_double * 3), ("vmax", C.c_double * 3),
+                ("edges", (C.c_double * NCLASS) * 3)]
+
+
+class KernelsC(C.Structure):
+    _fields_ = [("p_kernel", C.c_double * NKERNEL), ("sigma_trans", C.c_double), ("sigma_transform", C.c_double),
+                ("max_delta", C.c_int32), ("_pad", C.c_int32)]
+
+
+PROPOSAL_DTYPE = np.dtype([("kernel", "<i4"), ("target", "<i4"), ("ax", "<i4"), ("ay", "<i4"),
+                           ("as", "<f8"), ("ar", "<f8"), ("aa", "<f8"), ("aux0", "<f8"), ("aux1", "<f8"),
+                           ("param_id", "<i4"), ("new_class", "<i4"), ("u_accept", "<f8")], align=True)
+STEPOUT_DTYPE = np.dtype([("dE", "<f8"), ("fwd", "<f8"), ("bwd", "<f8"), ("log_alpha", "<f8"), ("T", "<f8"),
+                          ("accepted", "<i4"), ("n_after", "<i4")], align=True)
+
+
+class MppError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmppgpu error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """Load libmppgpu.so and declare the prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback for the sampler")
+    L = C.CDLL(path)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    protos = {
+        "mpp_create": (i32, [i32, C.POINTER(vp)]),
+        "mpp_destroy": (i32, [vp]),
+        "mpp_last_error": (C.c_char_p, [vp]),
+        "mpp_set_stream": (i32, [vp, vp]),
+        "mpp_synchronize": (i32, [vp]),
+        "mpp_set_option": (i32, [vp, C.c_char_p, i64]),
+        "mpp_get_option": (i64, [vp, C.c_char_p]),
+        "mpp_set_maps": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32]),
+        "mpp_set_model": (i32, [vp, C.POINTER(ModelC), C.POINTER(MappingsC)]),
+        "mpp_set_kernels": (i32, [vp, C.POINTER(KernelsC), vp]),
+        "mpp_set_points": (i32, [vp, i32, i32, vp, vp]),
+        "mpp_get_points": (i32, [vp, i32, i32, C.POINTER(C.c_int32), vp, vp]),
+        "mpp_count": (i32, [vp, i32, C.POINTER(C.c_int32)]),
+        "mpp_total_energy": (i32, [vp, i32, C.POINTER(dbl), vp]),
+        "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "mpp_papangelou": (i32, [vp, i32, vp]),
+        "mpp_naive_init": (i32, [vp, dbl, dbl]),
+        "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
+        "mpp_replay": (i32, [vp, i32, i32, vp, vp]),
+        "mpp_run": (i32, [vp, i64, C.c_uint64, C.c_uint32, i32, vp, vp]),
+        "mpp_step_index": (i32, [vp, i32, C.POINTER(C.c_int64)]),
+        "mpp_last_kernel_ms": (i32, [vp, C.POINTER(dbl)]),
+        "mpp_posnet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, dbl, dbl, vp]),
+        "mpp_shapenet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "mpp_philox4x32": (None, [vp, vp, vp]),
+        "mpp_abi_version": (i32, []),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    if path == LIB_PATH:
+        _lib = L
+    return L
+
+
+def model_struct(desc: ModelDesc) -> ModelC:
+    m = ModelC()
+    m.n_unit, m.n_pair = len(desc.unit), len(desc.pair)
+    m.combinator, m.gate_term, m.gate_thr, m.lin0 = desc.combinator, desc.gate_term, desc.gate_thr, desc.lin0
+    for i, (kind, gated, coef, params) in enumerate(desc.unit):
+        m.unit[i].kind, m.unit[i].gated, m.unit[i].coef = kind, gated, coef
+        for j, p in enumerate(params):
+            m.unit[i].p[j] = p
+    for i, (kind, gated, red, coef, max_dist, params) in enumerate(desc.pair):
+        t = m.pair[i]
+        t.kind, t.gated, t.reduce, t.coef, t.max_dist = kind, gated, red, coef, max_dist
+        for j, p in enumerate(params):
+            t.p[j] = p
+    return m
+
+
+def mappings_struct(mappings) -> MappingsC:
+    s = MappingsC()
+    for j, mp in enumerate(mappings):
+        if mp.n_classes != NCLASS:
+            raise ValueError("marks must have 32 classes")
+        s.cyclic[j], s.vmin[j], s.vmax[j] = int(mp.is_cyclic), float(mp.v_min), float(mp.v_max)
+        for i in range(NCLASS):
+            s.edges[j][i] = float(mp.feature_mapping[i])
+    return s
+
+
+def kernels_struct(kd: KernelDesc) -> KernelsC:
+    k = KernelsC()
+    for i in range(NKERNEL):
+        k.p_kernel[i] = float(kd.p_kernel[i])
+    k.sigma_trans, k.sigma_transform, k.max_delta = float(kd.sigma_trans), float(kd.sigma_transform), int(kd.max_delta)
+    return k
+
+
+def _is_torch(a) -> bool:
+    return hasattr(a, "data_ptr") and hasattr(a, "device")
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if _is_torch(a):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class MppContext:
+    """One GPU context holding ``n_tiles`` tiles of equal shape (thin, 1:1 over the C ABI)."""
+
+    def __init__(self, device: int = 0, point_capacity: Optional[int] = None, cell_capacity: Optional[int] = None,
+                 spec_waves: Optional[int] = None):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.mpp_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MppError(rc, "mpp_create failed: no usable MI355X/HIP device" if rc == -3 else "mpp_create failed")
+        self._h = h
+        self._keep = []          # keeps borrowed device tensors / host arrays alive
+        self.n_tiles = 0
+        self.shape = (0, 0)
+        self.n_terms = 0
+        self.names: List[str] = []
+        if point_capacity is not None:
+            self.set_option("point_capacity", point_capacity)
+        if cell_capacity is not None:
+            self.set_option("cell_capacity", cell_capacity)
+        if spec_waves is not None:
+            self.set_option("spec_waves", spec_waves)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise MppError(rc, self._L.mpp_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.mpp_destroy(self._h)
+            self._h = None
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        self._check(self._L.mpp_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        return int(self._L.mpp_get_option(self._h, name.encode()))
+
+    def set_stream(self, stream_handle: Optional[int]):
+        self._check(self._L.mpp_set_stream(self._h, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def synchronize(self):
+        self._check(self._L.mpp_synchronize(self._h))
+
+    # -- inputs --------------------------------------------------------------------------------
+    def set_maps(self, det, marks: Sequence):
+        """det: [T,H,W] or [H,W]; marks: three [T,H,W,32] or [H,W,32]; numpy (copied) or torch
+        tensors already on this GPU (borrowed, zero-copy)."""
+        on_device = _is_torch(det)
+        if on_device:
+            if any(not _is_torch(m) for m in marks):
+                raise TypeError("det and marks must all be device tensors or all be numpy arrays")
+            import torch
+            arrs = [a.contiguous() if a.dtype == torch.float32 else a.float().contiguous() for a in [det] + list(marks)]
+            if not all(a.is_cuda for a in arrs):
+                raise TypeError("torch maps must live on the GPU")
+            shape = tuple(arrs[0].shape)
+        else:
+            arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in [det] + list(marks)]
+            shape = arrs[0].shape
+        if len(shape) == 2:
+            T, (H, W) = 1, shape
+        else:
+            T, H, W = shape
+        for a in arrs[1:]:
+            if tuple(a.shape[-3:]) != (H, W, NCLASS):
+                raise ValueError(f"mark map of shape {tuple(a.shape)} does not match tile {H}x{W}x32")
+        self._check(self._L.mpp_set_maps(self._h, T, H, W, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]),
+                                         1 if on_device else 0))
+        self._keep = arrs if on_device else []
+        self.n_tiles, self.shape = T, (H, W)
+
+    def set_model(self, desc: ModelDesc, mappings):
+        m, mp = model_struct(desc), mappings_struct(mappings)
+        self._check(self._L.mpp_set_model(self._h, C.byref(m), C.byref(mp)))
+        self.n_terms = len(desc.unit) + len(desc.pair)
+        self.names = list(desc.names)
+
+    def set_kernels(self, kd: KernelDesc, intensity=None):
+        k = kernels_struct(kd)
+        inten = np.ascontiguousarray(np.broadcast_to(np.asarray(kd.intensity if intensity is None else intensity,
+                                                                dtype=np.float64), (max(self.n_tiles, 1),)))
+        self._check(self._L.mpp_set_kernels(self._h, C.byref(k), _ptr(inten)))
+
+    def set_schedule(self, T0: float, alpha: float, T_target: float = 0.0):
+        self._check(self._L.mpp_set_schedule(self._h, float(T0), float(alpha), float(T_target)))
+
+    # -- configuration -------------------------------------------------------------------------
+    def set_points(self, tile: int, xy, marks):
+        xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)
+        marks = np.ascontiguousarray(marks, dtype=np.float64).reshape(-1, 3)
+        self._check(self._L.mpp_set_points(self._h, tile, len(xy), _ptr(xy), _ptr(marks)))
+
+    def count(self, tile: int = 0) -> int:
+        n = C.c_int32()
+        self._check(self._L.mpp_count(self._h, tile, C.byref(n)))
+        return n.value
+
+    def get_points(self, tile: int = 0):
+        n = self.count(tile)
+        xy, marks = np.zeros((n, 2), np.int32), np.zeros((n, 3), np.float64)
+        nn = C.c_int32()
+        self._check(self._L.mpp_get_points(self._h, tile, n, C.byref(nn), _ptr(xy), _ptr(marks)))
+        return xy, marks
+
+    def naive_init(self, threshold: float, nms_distance: float = 6.0):
+        self._check(self._L.mpp_naive_init(self._h, float(threshold), float(nms_distance)))
+
+    # -- energies ------------------------------------------------------------------------------
+    def total_energy(self, tile: int = 0, return_vectors: bool = False):
+        e = C.c_double()
+        vec = np.zeros((self.count(tile), self.n_terms), np.float64) if return_vectors else None
+        self._check(self._L.mpp_total_energy(self._h, tile, C.byref(e), _ptr(vec)))
+        return (e.value, vec) if return_vectors else e.value
+
+    def delta_batch(self, tile: int, removals: Sequence[Sequence[int]], add_xy: Sequence, add_marks: Sequence):
+        n = len(removals)
+        rem_off = np.zeros(n + 1, np.int32)
+        add_off = np.zeros(n + 1, np.int32)
+        rem_off[1:] = np.cumsum([len(r) for r in removals])
+        add_off[1:] = np.cumsum([len(a) for a in add_xy])
+        rem = np.ascontiguousarray(np.concatenate([np.asarray(r, np.int32).reshape(-1) for r in removals] +
+                                                  [np.zeros(0, np.int32)]), dtype=np.int32)
+        axy = np.ascontiguousarray(np.concatenate([np.asarray(a, np.int32).reshape(-1, 2) for a in add_xy] +
+                                                  [np.zeros((0, 2), np.int32)]), dtype=np.int32)
+        am = np.ascontiguousarray(np.concatenate([np.asarray(a, np.float64).reshape(-1, 3) for a in add_marks] +
+                                                 [np.zeros((0, 3))]), dtype=np.float64)
+        if len(rem) == 0:
+            rem = np.zeros(1, np.int32)
+        if len(axy) == 0:
+            axy, am = np.zeros((1, 2), np.int32), np.zeros((1, 3))
+        out = np.zeros(n, np.float64)
+        self._check(self._L.mpp_delta_batch(self._h, tile, n, _ptr(rem_off), _ptr(rem), _ptr(add_off), _ptr(axy),
+                                            _ptr(am), _ptr(out)))
+        return out
+
+    def papangelou(self, tile: int = 0) -> np.ndarray:
+        out = np.zeros(max(self.count(tile), 1), np.float64)
+        self._check(self._L.mpp_papangelou(self._h, tile, _ptr(out)))
+        return out[:self.count(tile)]
+
+    # -- the chain -----------------------------------------------------------------------------
+    def replay(self, tile: int, tape: np.ndarray) -> np.ndarray:
+        tape = np.ascontiguousarray(tape, dtype=PROPOSAL_DTYPE)
+        out = np.zeros(len(tape), STEPOUT_DTYPE)
+        self._check(self._L.mpp_replay(self._h, tile, len(tape), _ptr(tape), _ptr(out)))
+        return out
+
+    def run(self, n_steps: int, seed: int, chain0: int = 0, trace_tile: int = -1):
+        if trace_tile >= 0:
+            out = np.zeros(n_steps, STEPOUT_DTYPE)
+            props = np.zeros(n_steps, PROPOSAL_DTYPE)
+            self._check(self._L.mpp_run(self._h, int(n_steps), int(seed), int(chain0), trace_tile, _ptr(out),
+                                        _ptr(props)))
+            return out, props
+        self._check(self._L.mpp_run(self._h, int(n_steps), int(seed), int(chain0), -1, None, None))
+        return None
+
+    def step_index(self, tile: int = 0) -> int:
+        s = C.c_int64()
+        self._check(self._L.mpp_step_index(self._h, tile, C.byref(s)))
+        return s.value
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double()
+        self._check(self._L.mpp_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # -- U-Net epilogues (device tensors) ---------------------------------------------------------
+    def posnet_epilogue(self, pos_out, H: int, W: int, div_w: float, div_b: float, det_out):
+        ldh, ldw = int(pos_out.shape[-2]), int(pos_out.shape[-1])
+        self._check(self._L.mpp_posnet_epilogue(self._h, H, W, ldh, ldw, _ptr(pos_out), float(div_w), float(div_b),
+                                                _ptr(det_out)))
+
+    def shapenet_epilogue(self, logits, H: int, W: int, marks_out):
+        ldh, ldw = int(logits.shape[-2]), int(logits.shape[-1])
+        self._check(self._L.mpp_shapenet_epilogue(self._h, H, W, ldh, ldw, _ptr(logits), _ptr(marks_out)))
+
+
+def philox(ctr, key) -> np.ndarray:
+    L = load_library()
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    o = np.zeros(4, np.uint32)
+    L.mpp_philox4x32(_ptr(c), _ptr(k), _ptr(o))
+    return o

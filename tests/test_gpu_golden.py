@@ -1,0 +1,106 @@
+"""HIP path against the vectors recorded from the reference and against the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import GOLDEN, Tape, model_for, sorted_rows
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import hip_api, mappings, synth
+
+pytestmark = pytest.mark.gpu
+TAPES = ["tape_hrc_64.npz", "tape_log_96.npz", "tape_hrc_128_gt.npz", "tape_log_64_empty.npz"]
+DE_ATOL, DE_RTOL, P_RTOL = 2e-6, 2e-6, 2e-5      # vs the reference (float32 arithmetic inside numpy)
+ORC_ATOL = 1e-9                                   # vs the float64 oracle
+
+
+def make_ctx(t: Tape, spec=1):
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec)
+    ctx.set_maps(t.det, t.marks)
+    ctx.set_model(t.model, mappings.default_mappings())
+    ctx.set_kernels(t.kernels)
+    ctx.set_points(0, t.init_xy, t.init_marks)
+    return ctx
+
+
+@pytest.mark.parametrize("spec", [1, 4, 8])
+@pytest.mark.parametrize("name", TAPES)
+def test_tape_replay(name, spec):
+    t = Tape(name)
+    ctx = make_ctx(t, spec)
+    assert ctx.total_energy() == pytest.approx(t.E0, rel=1e-6, abs=1e-6)
+    p = t.params
+    ctx.set_schedule(p["init_temperature"], p["alpha_t"], p["target_temperature"])
+    out = ctx.replay(0, t.proposals)
+    # 1. against the reference's recorded chain
+    np.testing.assert_array_equal(out["accepted"], t.col("accepted").astype(int))
+    np.testing.assert_array_equal(out["n_after"], t.col("n_after").astype(int))
+    np.testing.assert_allclose(out["T"], t.col("T"), rtol=1e-12)
+    np.testing.assert_allclose(out["dE"], t.col("dE"), rtol=DE_RTOL, atol=DE_ATOL)
+    np.testing.assert_allclose(out["fwd"], t.col("fwd"), rtol=P_RTOL, atol=1e-300)
+    np.testing.assert_allclose(out["bwd"], t.col("bwd"), rtol=P_RTOL, atol=1e-300)
+    xy, marks = ctx.get_points()
+    got = np.concatenate([xy.astype(float), marks], axis=1)
+    np.testing.assert_array_equal(got, t.final_by_slots)           # same slots, same order
+    # 2. against the float64 oracle, much tighter
+    o = oracle.Oracle(t.shape, t.det, t.marks, t.model, t.kernels)
+    o.set_points(t.init_xy, t.init_marks)
+    o.set_temperature(p["init_temperature"], p["alpha_t"], p["target_temperature"])
+    ref = o.replay(t.proposals)
+    np.testing.assert_allclose(out["dE"], ref["dE"], rtol=1e-9, atol=ORC_ATOL)
+    np.testing.assert_allclose(out["log_alpha"], ref["log_alpha"], rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(out["fwd"], ref["fwd"], rtol=1e-9)
+    np.testing.assert_allclose(out["bwd"], ref["bwd"], rtol=1e-9)
+    # 3. the incremental bookkeeping of the chain equals a from-scratch evaluation of its final state
+    assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-9)
+
+
+@pytest.mark.parametrize("name", ["tape_hrc_64.npz", "tape_log_96.npz"])
+def test_naive_init(name):
+    t = Tape(name)
+    ctx = make_ctx(t)
+    ctx.naive_init(t.setup.detection_threshold, 6.0)
+    xy, marks = ctx.get_points()
+    got = np.concatenate([xy.astype(float), marks], axis=1)
+    np.testing.assert_allclose(sorted_rows(got), sorted_rows(t.init), rtol=0, atol=1e-12)
+    o = oracle.Oracle(t.shape, t.det, t.marks, t.model, t.kernels)
+    oxy, omarks = o.naive_detection(t.setup.detection_threshold, 6.0)
+    np.testing.assert_array_equal(xy, oxy)                          # same greedy order as the oracle
+    np.testing.assert_array_equal(marks, omarks)
+
+
+@pytest.mark.parametrize("tag,setup_name", [("hrc", "legacy"), ("log", "no-calibration")])
+def test_delta_cases(tag, setup_name):
+    z = np.load(f"{GOLDEN}/delta_cases.npz", allow_pickle=False)
+    g = lambda k: z[f"{tag}_{k}"]
+    det = g("det")
+    _, marks = synth.render_maps(det.shape, g("gt_xy"), g("gt_marks"), noise=float(z["noise"]),
+                                 noise_seed=int(z["noise_seed"]))
+    setup, comb, model = model_for(setup_name)
+    base = g("base")
+    ctx = hip_api.MppContext(0, point_capacity=256)
+    ctx.set_maps(det, marks)
+    ctx.set_model(model, mappings.default_mappings())
+    ctx.set_points(0, base[:, :2].astype(np.int32), base[:, 2:])
+    e0, vec = ctx.total_energy(return_vectors=True)
+    assert e0 == pytest.approx(float(g("E0")), rel=1e-6, abs=1e-6)
+    order = [ctx.names.index(str(n)) for n in g("names")]
+    np.testing.assert_allclose(vec[:, order], g("vec"), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(ctx.papangelou(), g("papangelou_dE"), rtol=2e-6, atol=2e-6)
+    rows = [tuple(r) for r in base]
+    add_off = np.concatenate([[0], np.cumsum(g("add_len"))])
+    rem_off = np.concatenate([[0], np.cumsum(g("rem_len"))])
+    adds = [g("add_flat")[add_off[i]:add_off[i + 1]] for i in range(len(g("dE")))]
+    rems = [[rows.index(tuple(r)) for r in g("rem_flat")[rem_off[i]:rem_off[i + 1]]] for i in range(len(g("dE")))]
+    d = ctx.delta_batch(0, rems, [a[:, :2].astype(np.int32) for a in adds], [a[:, 2:] for a in adds])
+    np.testing.assert_allclose(d, g("dE"), rtol=2e-6, atol=5e-6)
+    # plain sum (no combinator)
+    unit, pair = setup.make_energies()
+    ctx.set_model(E.build_model_desc(unit, pair, None), mappings.default_mappings())
+    assert ctx.total_energy() == pytest.approx(float(g("E0_sum")), rel=1e-6, abs=1e-5)
+    # the reference's own criterion (test_perturbation_sampler.py:99): delta == E(x+u) - E(x)
+    ctx.set_model(model, mappings.default_mappings())
+    for i in (0, 7, 19):
+        keep = [r for j, r in enumerate(rows) if j not in rems[i]] + [tuple(r) for r in adds[i]]
+        new = np.array(keep, dtype=float).reshape(-1, 5)
+        ctx.set_points(0, new[:, :2].astype(np.int32), new[:, 2:])
+        assert abs(d[i] - (ctx.total_energy() - e0)) < 1e-8

@@ -1,0 +1,108 @@
+"""The reference's known answers through the C ABI on the GPU (same scenarios as
+test_oracle_reference_kat.py; reference test/test_energy_graph.py:94-244,
+test/test_interacting_points_set.py:149-272)."""
+import numpy as np
+import pytest
+
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import hip_api, mappings
+
+pytestmark = pytest.mark.gpu
+Z3 = [[0.0, 0.0, 0.0]]
+
+
+def make(shape, unit_value, pair_kind, max_dist):
+    ctx = hip_api.MppContext(0, point_capacity=64)
+    H, W = shape
+    ctx.set_maps(np.zeros((H, W), np.float32), [np.zeros((H, W, 32), np.float32)] * 3)
+    unit = [E.UnitTerm("U", E.U_CONST, [unit_value])]
+    pair = [E.PairTerm("P", pair_kind, max_dist=max_dist, reduce=E.REDUCE_MAX)]
+    ctx.set_model(E.build_model_desc(unit, pair, None), mappings.default_mappings())
+    return ctx
+
+
+def setp(ctx, pts):
+    ctx.set_points(0, np.array(pts, dtype=np.int32).reshape(-1, 2), np.zeros((len(pts), 3)))
+
+
+def delta(ctx, rem=(), add=None):
+    return float(ctx.delta_batch(0, [list(rem)], [add if add is not None else []],
+                                 [Z3 if add is not None else []])[0])
+
+
+def test_total_energy_energy_graph():
+    ctx = make((64, 64), -10.0, E.P_DIST_LE, 1.0)
+    pts = []
+    setp(ctx, pts)
+    assert ctx.total_energy() == 0.0
+    for p, expect in (((10, 10), -10.0), ((10, 11), -18.0), ((20, 20), -28.0)):
+        pts.append(p)
+        setp(ctx, pts)
+        assert ctx.total_energy() == expect
+    pts.remove((10, 11))
+    setp(ctx, pts)
+    assert ctx.total_energy() == -20.0
+
+
+def test_compute_delta_energy_graph():
+    ctx = make((64, 64), -10.0, E.P_DIST_LE, 1.0)
+    pts = []
+    setp(ctx, pts)
+    assert delta(ctx, add=[[10, 10]]) == -10.0
+    pts.append((10, 10)); setp(ctx, pts)
+    assert delta(ctx, add=[[10, 11]]) == -8.0
+    pts.append((10, 11)); setp(ctx, pts)
+    assert delta(ctx, add=[[20, 20]]) == -10.0
+    pts.append((20, 20)); setp(ctx, pts)
+    assert delta(ctx, rem=[2], add=[[10, 12]]) == 1.0
+    pts[2] = (10, 12); setp(ctx, pts)
+    assert delta(ctx, add=[[5, 5]]) == -10.0
+    pts.append((5, 5)); setp(ctx, pts)
+    assert delta(ctx, add=[[5, 6]]) == -8.0
+    pts.append((5, 7)); setp(ctx, pts)
+    assert delta(ctx, rem=[4], add=[[5, 8]]) == 0.0
+    pts[4] = (5, 8); setp(ctx, pts)
+    assert delta(ctx, rem=[1]) == 7.0
+
+
+def test_interacting_points_set_energies():
+    ctx = make((10, 10), 1.0, E.P_DIST_LT, 3.0)
+    setp(ctx, [(0, 0), (0, 1), (0, 4)])
+    assert ctx.total_energy() == 5.0
+    setp(ctx, [(0, 0), (0, 1), (0, 4), (0, 5)])
+    assert ctx.total_energy() == 8.0
+    setp(ctx, [(0, 0), (0, 1), (1, 0)])
+    assert ctx.total_energy() == 6.0
+    setp(ctx, [(0, 0), (0, 1), (0, 5)])
+    e0 = ctx.total_energy()
+    assert e0 == 5.0
+    assert delta(ctx, rem=[2]) == -1.0
+    assert delta(ctx, rem=[2], add=[[1, 0]]) == 1.0
+
+
+def test_the_chain_kernel_agrees_on_the_kat_moves():
+    """The same birth / move / death sequence replayed through the LDS-resident chain kernel
+    (always accepted: T is huge and u_accept tiny)."""
+    ctx = make((64, 64), -10.0, E.P_DIST_LE, 1.0)
+    setp(ctx, [])
+    ctx.set_schedule(1e9, 1.0, 0.0)
+    tape = np.zeros(8, hip_api.PROPOSAL_DTYPE)
+    moves = [(0, -1, 10, 10), (0, -1, 10, 11), (0, -1, 20, 20), (4, 2, 10, 12), (0, -1, 5, 5), (0, -1, 5, 7),
+             (4, 4, 5, 8), (1, 1, 0, 0)]
+    for rec, (k, t, x, y) in zip(tape, moves):
+        rec["kernel"], rec["target"], rec["ax"], rec["ay"], rec["u_accept"] = k, t, x, y, 1e-12
+    ctx.set_kernels(__import__("mpp_cnn_rs_object_detection_amd").kernels.make_kernels(mappings.default_mappings(), 1.0))
+    out = ctx.replay(0, tape)
+    assert list(out["dE"]) == [-10.0, -8.0, -10.0, 1.0, -10.0, -10.0, 0.0, 7.0]
+    assert list(out["accepted"]) == [1] * 8
+    assert ctx.count() == 4
+    assert ctx.total_energy() == -40.0
+
+
+def test_out_of_bounds_and_missing_point_errors():
+    ctx = make((10, 10), 1.0, E.P_DIST_LT, 3.0)
+    with pytest.raises(hip_api.MppError):         # point_set.py:99
+        setp(ctx, [(10, 3)])
+    setp(ctx, [(1, 1)])
+    with pytest.raises(hip_api.MppError):         # KeyError of energy_point_set.py:88-100
+        delta(ctx, rem=[3])
