@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Bench of the MPP / RJMCMC sampling hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): ONE 512x512 synthetic tile with ~200 objects, mpp_hrcM
+energies, the reference schedule T0=1, alpha=0.999, burn_in=99744 + 2*128 samples -> 100 001
+RJMCMC steps.  One bench "step" = one complete chain from the naive initialisation.  With
+--gpus N every rank samples its own tile (weak scaling) and the detections are all-gathered.
+
+Prints ONE JSON line (rank 0).  `value` = proposals/s over the whole job with the score maps
+already resident in HBM.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_model():
+    from mpp_cnn_rs_object_detection_amd import energies
+    setup = energies.LegacyEnergySetup()
+    setup.load_calibration(os.path.join(REPO, "models_storage", "mpp", "mpp_hrcM"))
+    with open(os.path.join(REPO, "model_configs", "mpp", "mpp_hrcM.json")) as f:
+        cfg = json.load(f)
+    comb = energies.hierarchical_from_manual(cfg["manual"])
+    unit, pair = setup.make_energies()
+    return setup, energies.build_model_desc(unit, pair, comb)
+
+
+def bytes_per_proposal(n_points: float, n_cells: int, acc: float) -> float:
+    """B = 20*(1+25*rho) + 245 + 20*acc  (state records of the 5x5 cells around the
+    proposal + score-map reads + write-back on accept)."""
+    rho = n_points / max(n_cells, 1)
+    return 20.0 * (1.0 + 25.0 * rho) + 245.0 + 20.0 * acc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=100001)
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--objects", type=int, default=200)
+    ap.add_argument("--spec", type=int, default=int(os.environ.get("MPP_SPEC_WAVES", "8")))
+    ap.add_argument("--tiles-per-gpu", type=int, default=1)
+    ap.add_argument("--cpu-baseline-chains", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from mpp_cnn_rs_object_detection_amd import distributed as mdist
+    from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings, synth
+
+    rank, world = mdist.init_process_group()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the sampler has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    setup, model = load_model()
+    maps = mappings.default_mappings()
+    T = args.tiles_per_gpu
+    tiles = [synth.make_tile(args.tile, args.objects, tile_id=rank * T + i) for i in range(T)]
+    ctx = hip_api.MppContext(local, point_capacity=1024, spec_waves=args.spec)
+    ctx.set_maps(np.stack([t.det for t in tiles]), [np.stack([t.marks[k] for t in tiles]) for k in range(3)])
+    ctx.set_model(model, maps)
+    ctx.naive_init(setup.detection_threshold, 6.0)
+    inits = [ctx.get_points(i) for i in range(T)]
+    intensity = np.array([max(1, len(xy)) for xy, _ in inits], dtype=np.float64)
+    kd = kernels.make_kernels(maps, 1.0)
+    ctx.set_kernels(kd, intensity=intensity)
+    T0, alpha, Tt = 1.0, 0.999, 0.0
+    n_cells = int(np.ceil(args.tile / 32)) ** 2
+
+    def one_chain(seed):
+        for i, (xy, mk) in enumerate(inits):
+            ctx.set_points(i, xy, mk)
+        ctx.set_schedule(T0, alpha, Tt)
+        ctx.run(args.iters, seed=seed, chain0=rank * T)
+        if world > 1:
+            pts = [ctx.get_points(i) for i in range(T)]
+            buf = mdist.pack_detections([rank * T + i for i in range(T)], pts, [None] * T, capacity=1024 * T)
+            mdist.all_gather_detections(buf, device=device)
+        return ctx.last_kernel_ms()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # acceptance rate and mean population for the algorithmic-bytes figure: one traced chain (untimed)
+    for i, (xy, mk) in enumerate(inits):
+        ctx.set_points(i, xy, mk)
+    ctx.set_schedule(T0, alpha, Tt)
+    tr_out, _ = ctx.run(args.iters, seed=0, chain0=rank * T, trace_tile=0)
+    acc = float(tr_out["accepted"].mean())
+    mean_n = float(tr_out["n_after"].mean())
+
+    for w in range(args.warmup):
+        one_chain(seed=w)
+    barrier()
+    t0 = time.perf_counter()
+    kms = []
+    for s in range(args.steps):
+        kms.append(one_chain(seed=s))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    proposals = world * T * args.steps * args.iters
+    value = proposals / elapsed
+    kernel_ms = float(np.mean(kms))
+    bpp = bytes_per_proposal(mean_n, n_cells, acc)
+    achieved = bpp * T * args.iters / (kernel_ms * 1e-3) / 1e9
+    final_xy, _ = ctx.get_points(0)
+    d = np.sqrt(((final_xy[:, None, :] - tiles[0].gt_xy[None]) ** 2).sum(-1)) if len(final_xy) else np.zeros((0, 1))
+    matched = int((d.min(axis=0) <= 2).sum()) if len(final_xy) else 0
+
+    result = {
+        "metric": "MPP proposals/s per 512x512 tile",
+        "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{T} x single {args.tile}x{args.tile} synthetic tile per GPU, {args.objects} objects, "
+                        f"mpp_hrcM energies, {args.iters} RJMCMC steps per chain (T0=1, alpha=0.999), naive init",
+            "iters_per_step": args.iters, "tiles_per_gpu": T, "spec_waves": args.spec,
+            "parallelism": f"tile-parallel x{world}, one all-gather of detections" if world > 1 else "1 tile, 1 workgroup",
+            "accept_rate": acc, "mean_points": mean_n, "final_points": int(len(final_xy)),
+            "gt_matched_within_2px": matched, "gt_objects": int(len(tiles[0].gt_xy)),
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_proposal": bpp,
+            "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle                     # the CPU restatement, timed as the baseline ("port")
+        o = oracle.Oracle(tiles[0].shape, tiles[0].det, tiles[0].marks, model,
+                          kernels.make_kernels(maps, float(intensity[0])))
+        t1 = time.perf_counter()
+        for s in range(args.cpu_baseline_chains):
+            o.set_points(*inits[0])
+            o.set_temperature(T0, alpha, Tt)
+            o.run(args.iters, s, chain=0)
+        dt = time.perf_counter() - t1
+        result["cpu_baseline"] = {
+            "value": args.cpu_baseline_chains * args.iters / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
+            "sample": f"{args.cpu_baseline_chains} chains x {args.iters} steps of the same tile "
+                      f"(oracle/mpp_oracle.c, gcc -O2, 1 thread, {os.cpu_count()} host cores present)",
+            "reference_python_probe": "0.73e3 proposals/s (reference NumPy sampler, 512x512/200 objects, 1 core of "
+                                      "the build container, BASELINE.md section 2; the reference cannot travel to the GPU box)",
+        }
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,16 @@
 #define ERR_BAD_TARGET 3
 #define ERR_CAND_OVERFLOW 4
 
+#ifdef MPP_PROFILE
+// diagnostic build only: cycles per phase of wave 0, summed over the launch (never in the product build)
+__device__ unsigned long long g_prof[16];
+#define PROF_T0() unsigned long long pt_ = clock64()
+#define PROF_ADD(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof_[i] += n_ - pt_; pt_ = n_; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(i)
+#endif
+
 struct Rec {                  // one speculative step
   int kernel, tidx, tslot, has_rem, has_add, valid;
   int ax, ay, rx, ry, pid, ncls;
@@ -571,8 +581,12 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
   long long step0 = *c.t.step, done = 0;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 
+#ifdef MPP_PROFILE
+  unsigned long long prof_[16] = {0};
+#endif
   while (done < n_steps && err == 0) {
     const int n = L.sh[0];
+    PROF_T0();
     // ---- phase A: wave w evaluates step done+w against the current state
     const long long my = done + c.wave;
     Rec r;
@@ -603,21 +617,25 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
         draw_proposal(c, w, n, r);
       }
+      PROF_ADD(0);
       if (r.valid) {
         if (r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
       }
       if (r.valid) {
         proposal_densities(c, r);
+        PROF_ADD(1);
         r.dE = 0.0;
         if (r.has_rem || r.has_add) {
           Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
           Geo ag = make_geo(add);
           double lin_a = 0.0; int gate_a = 1;
           if (r.has_add) unit_part(P, c.t, add, ag, &lin_a, &gate_a, nullptr);
+          PROF_ADD(2);
           double ra0, ra1;
           int e2 = 0;
           r.dE = eval_delta<false>(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, lin_a, gate_a, &ra0, &ra1, &e2);
           if (e2) { r.valid = 0; r.kernel = -2 - e2; }
+          PROF_ADD(3);
         }
       }
     }
@@ -642,6 +660,7 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
         green_terms(P, q, cur_n, c.t.intensity, &fwd, &bwd);
         double log_alpha = (-q.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN);
         int accepted = log(q.u_acc + EPS_GREEN) < log_alpha ? 1 : 0;
+        PROF_ADD(4);
         if (accepted && (q.has_rem || q.has_add)) {
           Rect add{q.ax, q.ay, q.as, q.ar, q.aa};
           Geo ag = make_geo(add);
@@ -697,6 +716,7 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
             wave_lds_fence();
           }
         }
+        PROF_ADD(5);
         if (tracing && c.lane == 0) {
           long long idx = done + w;
           if (out) {
@@ -723,7 +743,11 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
     err = L.sh[1];
     done += L.sh[2];
     if (SPEC > 1) __syncthreads();
+    PROF_ADD(6);
   }
+#ifdef MPP_PROFILE
+  if (tid == 0) for (int i = 0; i < 16; ++i) g_prof[i] = prof_[i];
+#endif
 
   // ---------------------------------------------------------------- write the configuration back
   const int n_end = L.sh[0];
@@ -737,6 +761,12 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
     *c.t.T = T;
   }
 }
+
+#ifdef MPP_PROFILE
+extern "C" void mpp_debug_read_prof(unsigned long long *out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+}
+#endif
 
 // ---- host-side launcher ----------------------------------------------------------------------------
 extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec) {

@@ -1,0 +1,19 @@
+import ctypes, sys, os, json
+import numpy as np
+sys.path.insert(0, os.getcwd())
+from mpp_cnn_rs_object_detection_amd import hip_api
+hip_api.LIB_PATH = os.path.join(os.getcwd(), 'mpp_cnn_rs_object_detection_amd', 'libmppgpu_prof.so')
+L = hip_api.load_library(hip_api.LIB_PATH); hip_api._lib = L
+import bench
+from mpp_cnn_rs_object_detection_amd import kernels, mappings, synth
+setup, model = bench.load_model(); maps = mappings.default_mappings()
+t = synth.make_tile(512, 200, 0)
+for spec in (1, 8):
+    ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=spec)
+    ctx.set_maps(t.det, t.marks); ctx.set_model(model, maps); ctx.naive_init(setup.detection_threshold, 6.0)
+    xy, mk = ctx.get_points(); ctx.set_kernels(kernels.make_kernels(maps, float(len(xy))))
+    ctx.set_schedule(1.0, 0.999, 0.0)
+    ctx.run(100001, seed=0)
+    buf = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof(buf)
+    v = np.array(list(buf), dtype=float); names = ['draw','dens','unit','evalD','green','apply','sync']
+    print('spec', spec, 'kernel ms', ctx.last_kernel_ms(), {n: round(x/100001) for n, x in zip(names, v)}, 'sum', round(v.sum()/100001), 'clock64 ticks/step')
