@@ -22,6 +22,7 @@ extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const
                                        double *dE);
 extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
                                double *scratch_rowtot);
+extern "C" void mpp_launch_boxsum(hipStream_t st, const double *rowpart, int H, int W, int md, double *boxsum);
 extern "C" void mpp_launch_naive_init(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles,
                                       double threshold, double nms_dist, unsigned long long *cand, int cand_cap);
 extern "C" void mpp_launch_posnet_epilogue(hipStream_t st, const float *out, int H, int W, int ldh, int ldw, float w,
@@ -42,7 +43,8 @@ struct mpp_ctx {
   int n_tiles = 0, H = 0, W = 0;
   bool maps_borrowed = false;
   float *det = nullptr, *m[3] = {nullptr, nullptr, nullptr};
-  double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr;
+  double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
+  bool box_dirty = true;
   int cap = 1024, cell_cap = 32, spec = 1;
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
@@ -118,6 +120,7 @@ static void free_tiles(mpp_ctx *c) {
     for (int k = 0; k < 3; ++k) if (c->m[k]) (void)hipFree(c->m[k]);
   }
   c->det = nullptr; c->m[0] = c->m[1] = c->m[2] = nullptr;
+  if (c->boxsum) { (void)hipFree(c->boxsum); c->boxsum = nullptr; }
   void *ptrs[] = {c->rowpart, c->rowbase, c->rowtot, c->px, c->py, c->n, c->errd, c->ps, c->pr, c->pa, c->T, c->step,
                   c->d_tiles};
   for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -188,6 +191,20 @@ static void refresh_grid(mpp_ctx *c) {
   P.nx = c->H > 0 ? (int)ceil((double)c->H / P.res) : 0;         // point_set.py:59-61
   P.ny = c->W > 0 ? (int)ceil((double)c->W / P.res) : 0;
   P.cap = c->cap; P.cell_cap = c->cell_cap; P.n_tiles = c->n_tiles;
+  P.res_int = (int)P.res;
+  P.res_shift = -1;
+  for (int s = 0; s < 16; ++s) if ((1 << s) == P.res_int) P.res_shift = s;
+  for (int p = 0; p < MPP_MAX_PAIR; ++p)
+    P.maxd2[p] = p < P.model.n_pair ? (int)floor(P.model.pair[p].max_dist * P.model.pair[p].max_dist + 1e-9) : 0;
+  P.conflict_d2 = (int)(4.0 * P.max_inter * P.max_inter) + 1;
+  P.uniform_bins = 1;
+  for (int k = 0; k < 3; ++k) {
+    double range = P.maps.vmax[k] - P.maps.vmin[k];
+    P.inv_step[k] = range > 0 ? (double)MPP_NCLASS / range : 0.0;
+    for (int i = 0; i < MPP_NCLASS; ++i)
+      if (!(fabs(P.maps.edges[k][i] - (P.maps.vmin[k] + range * i / MPP_NCLASS)) <= 1e-9 * (fabs(range) + 1.0)))
+        P.uniform_bins = 0;
+  }
   c->params_dirty = true;
 }
 
@@ -204,6 +221,15 @@ extern "C" int mpp_set_model(mpp_ctx *c, const mpp_model *model, const mpp_mappi
     if (!ok) return fail(c, -1, "pair term %d: unsupported (kind, reduce) combination", p);
     if (!(t.max_dist > 0.0)) return fail(c, -1, "pair term %d: max_dist must be positive", p);
   }
+  {
+    double maxd = 0.0;
+    for (int p = 0; p < model->n_pair; ++p) if (model->pair[p].max_dist > maxd) maxd = model->pair[p].max_dist;
+    if (maxd > 32.0 && maxd != floor(maxd))
+      return fail(c, -1, "interaction radius %g > 32 must be integral (it is the cell size of the spatial hash)", maxd);
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int i = 1; i < MPP_NCLASS; ++i)
+      if (!(maps->edges[k][i] > maps->edges[k][i - 1])) return fail(c, -1, "mark %d: bin edges must increase", k);
   c->hp.model = *model;
   c->hp.maps = *maps;
   c->have_model = true;
@@ -220,6 +246,7 @@ extern "C" int mpp_set_kernels(mpp_ctx *c, const mpp_kernels *k, const double *i
   }
   if (fabs(acc - 1.0) > 1e-8) return fail(c, -1, "kernel probabilities do not sum to 1");   // make_kernels.py:164-172
   if (k->max_delta < 0 || k->max_delta > 15) return fail(c, -1, "max_delta must be in 0..15");
+  if (!c->have_kernels || c->hp.kern.max_delta != k->max_delta) c->box_dirty = true;
   c->hp.kern = *k;
   c->have_kernels = true;
   c->params_dirty = true;
@@ -256,6 +283,8 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   HIPCHK(c, dalloc(&c->rowpart, T * hw));
   HIPCHK(c, dalloc(&c->rowbase, T * (H + 1)));
   HIPCHK(c, dalloc(&c->rowtot, T * H));
+  HIPCHK(c, dalloc(&c->boxsum, T * hw));
+  c->box_dirty = true;
   HIPCHK(c, dalloc(&c->px, T * c->cap)); HIPCHK(c, dalloc(&c->py, T * c->cap));
   HIPCHK(c, dalloc(&c->ps, T * c->cap)); HIPCHK(c, dalloc(&c->pr, T * c->cap)); HIPCHK(c, dalloc(&c->pa, T * c->cap));
   HIPCHK(c, dalloc(&c->n, T)); HIPCHK(c, dalloc(&c->errd, T)); HIPCHK(c, dalloc(&c->T, T * 3));
@@ -289,6 +318,7 @@ static int push_state(mpp_ctx *c) {
       r.det = c->det + t * hw;
       for (int k = 0; k < 3; ++k) r.m[k] = c->m[k] + t * hw * MPP_NCLASS;
       r.rowpart = c->rowpart + t * hw; r.rowbase = c->rowbase + (size_t)t * (c->H + 1);
+      r.boxsum = c->boxsum + t * hw;
       r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
@@ -298,6 +328,13 @@ static int push_state(mpp_ctx *c) {
                              c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tiles_dirty = false;
+  }
+  if (c->box_dirty && c->have_kernels) {
+    const size_t hw = (size_t)c->H * c->W;
+    for (int t = 0; t < c->n_tiles; ++t)
+      mpp_launch_boxsum(c->stream, c->rowpart + t * hw, c->H, c->W, c->hp.kern.max_delta, c->boxsum + t * hw);
+    HIPCHK(c, hipGetLastError());
+    c->box_dirty = false;
   }
   if (c->params_dirty) {
     c->hp.cap = c->cap; c->hp.cell_cap = c->cell_cap; c->hp.n_tiles = c->n_tiles;
@@ -487,9 +524,10 @@ extern "C" int mpp_set_schedule(mpp_ctx *c, double T0, double alpha, double T_ta
 
 static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t seed, uint32_t chain0,
                      const mpp_proposal *d_tape, int trace_tile, mpp_step_out *d_out, mpp_proposal *d_props) {
+  if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   int rc = push_state(c);
   if (rc) return rc;
-  if (!d_tape && !c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
+  if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   const int ncell = c->hp.nx * c->hp.ny;
   size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, c->spec);
   if (lds > MPP_LDS_LIMIT)

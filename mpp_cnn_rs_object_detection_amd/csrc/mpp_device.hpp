@@ -29,7 +29,13 @@ struct DevParams {
   double max_inter;     // largest pair max_dist (energy_graph.py:26-29)
   double res;           // cell size = max(max_inter, 32) (point_set.py:58)
   int32_t H, W, nx, ny; // grid dims (point_set.py:59-61)
-  int32_t cap, cell_cap, n_tiles, _pad;
+  int32_t cap, cell_cap, n_tiles, res_int;
+  int32_t res_shift;    // log2(res_int) if it is a power of two, else -1
+  int32_t uniform_bins; // the mark edges are linspace(vmin,vmax,33)[:-1] (checked on the host)
+  int32_t maxd2[MPP_MAX_PAIR];   // floor(max_dist^2): d <= max_dist  <=>  d2 <= maxd2 for integer d2
+  int32_t conflict_d2;  // (2*max_inter)^2 + 1: two proposals further apart cannot influence each other
+  int32_t _pad2;
+  double inv_step[3];   // 32 / (vmax - vmin)
 };
 
 // per-tile device pointers
@@ -38,6 +44,7 @@ struct TileRef {
   const float *m[3];
   const double *rowpart;   // [H][W] inclusive partial sums of det within each row
   const double *rowbase;   // [H+1] exclusive prefix of row totals; rowbase[H] = sum(det)
+  const double *boxsum;    // [H][W] sum of det over the (2*max_delta+1)^2 window clipped to the tile
   // point configuration, dense slots (capacity cap)
   int32_t *px, *py;
   double *ps, *pr, *pa;
@@ -134,31 +141,54 @@ __device__ __forceinline__ bool rect_less(int ax, int ay, double as, double ar, 
   return aa < ba;
 }
 
-// RectangleOverlapEnergy (prior_energies.py:11-24); `first` tells whether u is the subject
-__device__ inline double overlap_energy(const Geo &u, const Geo &v, bool u_first) {
+#ifdef MPP_PROFILE
+__device__ unsigned long long g_clip_count;
+#endif
+// RectangleOverlapEnergy (prior_energies.py:11-24); `u_first` tells whether u is the subject;
+// ru, rv: circumscribed-circle radii, d2: squared centre distance
+__device__ inline double overlap_energy_r(const Geo &u, const Geo &v, bool u_first, double ru, double rv, double d2) {
   double A = geo_area(u), B = geo_area(v);
   double mn = A < B ? A : B;
   if (mn < DEGENERATE_AREA) return 0.0;
-  double dx = (double)(u.x - v.x), dy = (double)(u.y - v.y);
-  double ru = sqrt(u.hl * u.hl + u.hw * u.hw), rv = sqrt(v.hl * v.hl + v.hw * v.hw);
   double reach = ru + rv;
-  if (dx * dx + dy * dy > reach * reach * 1.0000001) return 0.0;   // circumscribed circles apart
+  if (d2 > reach * reach * 1.0000001) return 0.0;                  // circumscribed circles apart
+#ifdef MPP_PROFILE
+  atomicAdd(&g_clip_count, 1ull);
+#endif
   double ax[4], ay[4], bx[4], by[4];
   if (u_first) { geo_corners(u, ax, ay); geo_corners(v, bx, by); }
   else { geo_corners(v, ax, ay); geo_corners(u, bx, by); }
   return clip_area(ax, ay, bx, by) / (mn + AREA_EPS);
 }
+__device__ __forceinline__ double geo_radius(const Geo &g) { return sqrt(g.hl * g.hl + g.hw * g.hw); }
+__device__ inline double overlap_energy(const Geo &u, const Geo &v, bool u_first) {
+  double dx = (double)(u.x - v.x), dy = (double)(u.y - v.y);
+  return overlap_energy_r(u, v, u_first, geo_radius(u), geo_radius(v), dx * dx + dy * dy);
+}
 
 __device__ __forceinline__ double sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
-// mappings.py:44-62: class = max{i : v >= edge_i}
-__device__ __forceinline__ int value_to_class(const DevParams *P, int k, double v) {
-  int lo = 0, hi = MPP_NCLASS;       // invariant: edges[lo] <= v (or lo == 0), edges[hi] > v
+// mappings.py:44-62: class = max{i : v >= edge_i}.  `edges` = the 32 lower bin edges of mark k
+// (HBM copy in DevParams or the chain's LDS copy).  For linspace bins the class is computed and
+// then corrected against the actual table, so the result is exactly the table's.
+__device__ __forceinline__ int value_to_class_tab(const DevParams *P, const double *edges, int k, double v) {
+  if (P->uniform_bins) {
+    int g = (int)floor((v - P->maps.vmin[k]) * P->inv_step[k]);
+    g = g < 0 ? 0 : (g > MPP_NCLASS - 1 ? MPP_NCLASS - 1 : g);
+    double e0 = edges[g], e1 = edges[g < MPP_NCLASS - 1 ? g + 1 : g];
+    if (v < e0) { if (g > 0) --g; }
+    else if (g < MPP_NCLASS - 1 && v >= e1) ++g;
+    return g;
+  }
+  int lo = 0, hi = MPP_NCLASS;
   while (hi - lo > 1) {
     int mid = (lo + hi) >> 1;
-    if (v >= P->maps.edges[k][mid]) lo = mid; else hi = mid;
+    if (v >= edges[mid]) lo = mid; else hi = mid;
   }
   return lo;
+}
+__device__ __forceinline__ int value_to_class(const DevParams *P, int k, double v) {
+  return value_to_class_tab(P, P->maps.edges[k], k, v);
 }
 __device__ __forceinline__ double mark_of(const Rect &q, int k) { return k == 0 ? q.s : (k == 1 ? q.r : q.a); }
 __device__ __forceinline__ void set_mark(Rect &q, int k, double v) {
@@ -168,29 +198,34 @@ __device__ __forceinline__ const float *mark_row(const DevParams *P, const TileR
   return t.m[k] + ((size_t)x * P->W + y) * MPP_NCLASS;
 }
 
-// one unit energy term of a rectangle
-__device__ inline double unit_value(const DevParams *P, const TileRef &t, const mpp_unit_term &u, const Rect &q,
-                                    const Geo &g) {
+// one unit energy term of a rectangle; `edges` = [3][32] table (HBM or LDS copy)
+__device__ inline double unit_value(const DevParams *P, const TileRef &t, const double *edges, const mpp_unit_term &u,
+                                    const Rect &q, const Geo &g) {
   switch (u.kind) {
     case MPP_U_POSITION: {
       float e = -2.0f * (t.det[(size_t)q.x * P->W + q.y] - (float)u.p[0]);   // float32, as numpy does
       return (double)e;
     }
     case MPP_U_SHAPE_REMAP: {
+      // the three class lookups, loads and sigmoids are independent chains: keep them side by side
+      const size_t pix = ((size_t)q.x * P->W + q.y) * MPP_NCLASS;
+      int c0 = value_to_class_tab(P, edges, 0, q.s), c1 = value_to_class_tab(P, edges + MPP_NCLASS, 1, q.r),
+          c2 = value_to_class_tab(P, edges + 2 * MPP_NCLASS, 2, q.a);
+      double p0 = (double)t.m[0][pix + c0], p1 = (double)t.m[1][pix + c1], p2 = (double)t.m[2][pix + c2];
+      double e0 = exp(-(p0 * u.p[0] + u.p[3])), e1 = exp(-(p1 * u.p[1] + u.p[4])), e2 = exp(-(p2 * u.p[2] + u.p[5]));
       double acc = 0.0;
-      for (int k = 0; k < 3; ++k) {
-        double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
-        acc += -2.0 * sigmoid_d(p * u.p[k] + u.p[3 + k]) + 1.0;
-      }
+      acc += -2.0 * (1.0 / (1.0 + e0)) + 1.0;
+      acc += -2.0 * (1.0 / (1.0 + e1)) + 1.0;
+      acc += -2.0 * (1.0 / (1.0 + e2)) + 1.0;
       return acc / 3.0;
     }
     case MPP_U_MARK_NEG: {
       int k = (int)u.p[0];
-      return -(double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
+      return -(double)mark_row(P, t, k, q.x, q.y)[value_to_class_tab(P, edges + k * MPP_NCLASS, k, mark_of(q, k))];
     }
     case MPP_U_MARK_REMAP: {
       int k = (int)u.p[0];
-      double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class(P, k, mark_of(q, k))];
+      double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class_tab(P, edges + k * MPP_NCLASS, k, mark_of(q, k))];
       return -2.0 * sigmoid_d(p * u.p[1] + u.p[2]) + 1.0;
     }
     case MPP_U_AREA: {
@@ -206,12 +241,12 @@ __device__ inline double unit_value(const DevParams *P, const TileRef &t, const 
 
 // the part of a point's combined energy that does not depend on its neighbours:
 // lin = lin0 + sum_units coef*g*v ; gate = [v_gate <= thr]
-__device__ inline void unit_part(const DevParams *P, const TileRef &t, const Rect &q, const Geo &g, double *lin,
-                                 int *gate, double *vec_or_null) {
+__device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
+                                 const Geo &g, double *lin, int *gate, double *vec_or_null) {
   const mpp_model &M = P->model;
   double v[MPP_MAX_UNIT];
   for (int k = 0; k < M.n_unit; ++k) {
-    v[k] = unit_value(P, t, M.unit[k], q, g);
+    v[k] = unit_value(P, t, edges, M.unit[k], q, g);
     if (vec_or_null) vec_or_null[k] = v[k];
   }
   int gt = 1;

@@ -25,6 +25,23 @@ __global__ void k_row_base(const double *rowtot, int H, double *rowbase) {
     rowbase[H] = s;
   }
 }
+// sum of det over the (2*md+1)^2 window clipped to the tile, around every pixel: the normaliser of the
+// data-driven translation kernel (transform_kernels.py:70-76,94-99).  Rows are added top to bottom,
+// each row segment taken from the per-row prefix table -- the same order the sampler's draw uses.
+__global__ void k_boxsum(const double *rowpart, int H, int W, int md, double *boxsum) {
+  int y = blockIdx.x * blockDim.x + threadIdx.x, x = blockIdx.y;
+  if (y >= W || x >= H) return;
+  int x0 = max(0, x - md), x1 = min(x + md + 1, H), y0 = max(0, y - md), y1 = min(y + md + 1, W);
+  double s = 0.0;
+  for (int r = x0; r < x1; ++r) {
+    const double *rp = rowpart + (size_t)r * W;
+    s += rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0);
+  }
+  boxsum[(size_t)x * W + y] = s;
+}
+extern "C" void mpp_launch_boxsum(hipStream_t st, const double *rowpart, int H, int W, int md, double *boxsum) {
+  hipLaunchKernelGGL(k_boxsum, dim3((W + 63) / 64, H), dim3(64), 0, st, rowpart, H, W, md, boxsum);
+}
 extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
                                double *scratch_rowtot) {
   hipLaunchKernelGGL(k_row_partial, dim3((H + 63) / 64), dim3(64), 0, st, det, H, W, rowpart, scratch_rowtot);

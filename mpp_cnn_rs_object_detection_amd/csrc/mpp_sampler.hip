@@ -6,21 +6,25 @@
 //
 // Design (MI355X-first):
 //  * one workgroup = one tile's chain; the whole interacting point set (marks, cached corner
-//    trig, per-point unit energy, per-point pair reductions) and the 32-px spatial hash live in LDS
-//    for the entire launch; HBM is touched only for score-map reads of the proposals;
-//  * one 64-lane wave evaluates one proposal: lanes take the candidate neighbours gathered from
-//    the 3x3 cells around the removed and the added point, compute the pair terms (rectangle
-//    clipping, alignment) against them and butterfly-reduce dE; mark rows (32 floats = 128 B) and
-//    detection-map windows are read one element per lane, i.e. coalesced;
+//    trig, circumradius, per-point unit energy, per-point pair reductions) and the 32-px spatial
+//    hash live in LDS for the entire launch; HBM is touched only for score-map reads of proposals;
+//  * one 64-lane wave evaluates one proposal: lanes take the candidate neighbours found in the
+//    3x3 cells around the removed and the added point and compute the pair terms (rectangle
+//    clipping, alignment) against them; only the few lanes whose neighbour actually changes feed
+//    the dE sum (ballot + readlane, no 64-wide butterflies);
 //  * instead of rebuilding edges twice per step like the reference, each point caches the
 //    max/min reduction of its pair energies; a removal that takes away a point's extremum
 //    triggers a cooperative re-scan of that point's neighbourhood;
+//  * a single dependent chain of float64 transcendentals is what a step costs, so their number is
+//    kept minimal (one exp for the accept test, trig reused when the angle does not change, ...);
 //  * SPEC waves evaluate the next SPEC steps of the SAME chain speculatively against the current
-//    state; wave 0 then commits them in order and throws away everything after the first accepted
-//    step that could have influenced a later one.  The chain is bit-for-bit the sequential one.
+//    state, each including its own accept decision and the list of neighbour updates it would
+//    cause; wave 0 then commits them in order (a few LDS writes per accepted step) and discards
+//    everything after the first accepted step that could have influenced a later one.
+//    The chain is bit-for-bit the sequential one for every SPEC.
 #include "mpp_device.hpp"
 
-#define CAND_MAX 640          // >= 18 cells x cell_cap(<=32) + slack; per-wave candidate list
+#define STASH 24              // neighbour updates remembered per speculative step
 #define ERR_CELL_OVERFLOW 1
 #define ERR_POINT_OVERFLOW 2
 #define ERR_BAD_TARGET 3
@@ -36,29 +40,36 @@ __device__ unsigned long long g_prof[16];
 #define PROF_ADD(i)
 #endif
 
-struct Rec {                  // one speculative step
+struct Rec {                  // one speculative step, fully evaluated
   int kernel, tidx, tslot, has_rem, has_add, valid;
   int ax, ay, rx, ry, pid, ncls;
+  int accepted, n_stash, gate_a, _pad;
   double as, ar, aa, aux0, aux1, u_acc, qf, qb, dE;
+  double hl, hw, ca, sa, rad, lin_a, ra0, ra1;   // derived data of the proposed point
+  double fwd, bwd, log_alpha;                    // filled only when the tile is traced
 };
 
 struct Lds {
-  double *s, *r, *a, *ca, *sa, *hl, *hw, *lin, *red0, *red1;
+  double *s, *r, *a, *ca, *sa, *hl, *hw, *rad, *lin, *red0, *red1;
+  double *edges;              // [3][32] copy of the mark bin edges
+  double *stash_v0, *stash_v1;
   int *xy;
-  unsigned short *order, *cell_items, *cell_cnt, *cand;
+  unsigned short *order, *cell_items, *cell_cnt, *stash_slot;
   unsigned char *gate;
   Rec *rec;
-  int *sh;                    // [0]=n [1]=err [2]=committed
+  int *sh;                    // [0]=n [1]=err [2]=committed ; sh[4..5] = T (double)
 };
 
 __host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, int spec) {
   size_t b = 0;
-  b += (size_t)10 * cap * sizeof(double);
+  b += (size_t)11 * cap * sizeof(double);
+  b += (size_t)3 * MPP_NCLASS * sizeof(double);
+  b += (size_t)2 * spec * STASH * sizeof(double);
   b += (size_t)cap * sizeof(int);
   b += (size_t)cap * sizeof(unsigned short);                  // order
   b += (size_t)ncell * cell_cap * sizeof(unsigned short);     // cell items
   b += (size_t)ncell * sizeof(unsigned short);                // cell counts
-  b += (size_t)spec * CAND_MAX * sizeof(unsigned short);      // candidate lists
+  b += (size_t)spec * STASH * sizeof(unsigned short);
   b += (size_t)cap;                                           // gate
   b = (b + 15) & ~(size_t)15;
   b += (size_t)spec * sizeof(Rec);
@@ -70,13 +81,16 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
   Lds L;
   double *d = (double *)base;
   L.s = d; d += cap; L.r = d; d += cap; L.a = d; d += cap; L.ca = d; d += cap; L.sa = d; d += cap;
-  L.hl = d; d += cap; L.hw = d; d += cap; L.lin = d; d += cap; L.red0 = d; d += cap; L.red1 = d; d += cap;
+  L.hl = d; d += cap; L.hw = d; d += cap; L.rad = d; d += cap; L.lin = d; d += cap; L.red0 = d; d += cap;
+  L.red1 = d; d += cap;
+  L.edges = d; d += 3 * MPP_NCLASS;
+  L.stash_v0 = d; d += (size_t)spec * STASH; L.stash_v1 = d; d += (size_t)spec * STASH;
   L.xy = (int *)d;
   unsigned short *u = (unsigned short *)(L.xy + cap);
   L.order = u; u += cap;
   L.cell_items = u; u += (size_t)ncell * cell_cap;
   L.cell_cnt = u; u += ncell;
-  L.cand = u; u += (size_t)spec * CAND_MAX;
+  L.stash_slot = u; u += (size_t)spec * STASH;
   L.gate = (unsigned char *)u;
   size_t off = (size_t)((unsigned char *)u + cap - base);
   off = (off + 15) & ~(size_t)15;
@@ -99,18 +113,29 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 
+__device__ __forceinline__ int cell_coord(const DevParams *P, int x) {
+  return P->res_shift >= 0 ? (x >> P->res_shift) : (x / P->res_int);
+}
 __device__ __forceinline__ int cell_index(const DevParams *P, int x, int y, int *ci, int *cj) {
-  int i = (int)floor((double)x / P->res), j = (int)floor((double)y / P->res);
+  int i = cell_coord(P, x), j = cell_coord(P, y);
   *ci = i; *cj = j;
   return j + i * P->ny;
 }
-__device__ __forceinline__ Geo load_geo(const Lds &L, int slot) {
-  Geo g;
+struct Geo2 { Geo g; double rad; };
+__device__ __forceinline__ Geo2 load_geo(const Lds &L, int slot) {
+  Geo2 o;
   int xy = L.xy[slot];
-  g.x = xy & 0xffff; g.y = (xy >> 16) & 0xffff;
-  g.hl = L.hl[slot]; g.hw = L.hw[slot]; g.ca = L.ca[slot]; g.sa = L.sa[slot];
-  return g;
+  o.g.x = xy & 0xffff; o.g.y = (xy >> 16) & 0xffff;
+  o.g.hl = L.hl[slot]; o.g.hw = L.hw[slot]; o.g.ca = L.ca[slot]; o.g.sa = L.sa[slot];
+  o.rad = L.rad[slot];
+  return o;
 }
 __device__ __forceinline__ Rect load_rect(const Lds &L, int slot) {
   Rect q;
@@ -126,26 +151,27 @@ __device__ __forceinline__ bool slot_first(const Lds &L, int u, const Geo &gu, i
   if (gu.y != vy) return gu.y < vy;
   return rect_less(gu.x, gu.y, L.s[u], L.r[u], L.a[u], vx, vy, vs, vr, va);
 }
-__device__ __forceinline__ double pair_value(const mpp_pair_term &pt, const Geo &u, const Geo &v, bool u_first,
-                                             double d) {
+// pair energy of (u, v); d2 = squared centre distance (integer valued)
+__device__ __forceinline__ double pair_value(const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v, bool u_first,
+                                             int d2) {
   switch (pt.kind) {
-    case MPP_P_OVERLAP: return overlap_energy(u, v, u_first);
-    case MPP_P_ALIGN: return 1.0 - fabs(u.ca * v.ca + u.sa * v.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
-    case MPP_P_DIST_LE: return d <= pt.max_dist ? 1.0 : 0.0;
-    case MPP_P_DIST_LT: return d < pt.max_dist ? 1.0 : 0.0;
+    case MPP_P_OVERLAP: return overlap_energy_r(u.g, v.g, u_first, u.rad, v.rad, (double)d2);
+    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
+    case MPP_P_DIST_LE: return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0;
+    case MPP_P_DIST_LT: return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0;
   }
   return 0.0;
 }
 
 // reduction of pair term p over the neighbours of slot u, skipping `skip`, optionally including
 // an extra rectangle (the proposal's new point).  Whole wave cooperates; result is uniform.
-__device__ double rescan_point(const Chain &c, int p, int u, int skip, bool has_add, const Rect &ar, const Geo &ag) {
+__device__ double rescan_point(const Chain &c, int p, int u, int skip, bool has_add, const Rect &ar, const Geo2 &ag) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
   const mpp_pair_term &pt = P->model.pair[p];
-  Geo gu = load_geo(L, u);
+  Geo2 gu = load_geo(L, u);
   int ci, cj;
-  cell_index(P, gu.x, gu.y, &ci, &cj);
+  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
   double acc = 0.0;                       // 0 is neutral for every supported (kind, reduce) pair
   for (int di = -1; di <= 1; ++di)
     for (int dj = -1; dj <= 1; ++dj) {
@@ -155,47 +181,91 @@ __device__ double rescan_point(const Chain &c, int p, int u, int skip, bool has_
       for (int e = c.lane; e < cnt; e += WAVE) {
         int w = L.cell_items[cell * P->cell_cap + e];
         if (w == u || w == skip) continue;
-        Geo gw = load_geo(L, w);
-        double dx = (double)(gu.x - gw.x), dy = (double)(gu.y - gw.y);
-        double d = sqrt(dx * dx + dy * dy);
-        if (d <= pt.max_dist) {
-          bool uf = slot_first(L, u, gu, gw.x, gw.y, L.s[w], L.r[w], L.a[w]);
-          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d));
+        Geo2 gw = load_geo(L, w);
+        int dx = gu.g.x - gw.g.x, dy = gu.g.y - gw.g.y, d2 = dx * dx + dy * dy;
+        if (d2 <= P->maxd2[p]) {
+          bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
+          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
         }
       }
     }
   if (has_add && c.lane == 0) {
-    double dx = (double)(gu.x - ag.x), dy = (double)(gu.y - ag.y);
-    double d = sqrt(dx * dx + dy * dy);
-    if (d <= pt.max_dist) {
-      bool uf = slot_first(L, u, gu, ar.x, ar.y, ar.s, ar.r, ar.a);
-      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d));
+    int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
+    if (d2 <= P->maxd2[p]) {
+      bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
     }
   }
   return wave_reduce(pt.reduce, acc);
 }
 
+// the same reduction computed by ONE lane on its own (used inside eval_delta: the few lanes whose
+// neighbour loses its extremum each walk that neighbour's 3x3 cells, all of them at the same time)
+__device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int skip, bool has_add, const Rect &ar,
+                              const Geo2 &ag) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const mpp_pair_term &pt = P->model.pair[p];
+  int ci, cj;
+  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
+  double acc = 0.0;
+  for (int di = -1; di <= 1; ++di)
+    for (int dj = -1; dj <= 1; ++dj) {
+      int i = ci + di, j = cj + dj;
+      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
+      int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      for (int e = 0; e < cnt; ++e) {
+        int w = L.cell_items[cell * P->cell_cap + e];
+        if (w == u || w == skip) continue;
+        int wxy = L.xy[w];
+        int dx = gu.g.x - (wxy & 0xffff), dy = gu.g.y - ((wxy >> 16) & 0xffff), d2 = dx * dx + dy * dy;
+        if (d2 <= P->maxd2[p]) {
+          Geo2 gw = load_geo(L, w);
+          bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
+          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
+        }
+      }
+    }
+  if (has_add) {
+    int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
+    if (d2 <= P->maxd2[p]) {
+      bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
+    }
+  }
+  return acc;
+}
+
 // dE of (remove slot `rem`, add rectangle `ar`) -- energy_graph.py:139-225 -- as
 //   sum over neighbours u of [e_u(after) - e_u(before)]  +  e_added - e_removed.
-// With APPLY the neighbours' cached reductions are updated in place.
-// ra0/ra1: pair reductions of the added point.  Uniform result.
+// The neighbours whose cached reductions change are written to the wave's stash
+// (slot, new0, new1) so that an accepted step is applied without re-evaluation;
+// *n_stash > STASH means the stash overflowed.  With APPLY the caches are updated directly.
+#ifdef MPP_PROFILE
+#define DPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0) atomicAdd(&g_prof2[i], n_ - dpt_); dpt_ = n_; } while (0)
+__device__ unsigned long long g_prof2[16];
+#else
+#define DPROF(i)
+#endif
 template <bool APPLY>
-__device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &ar, const Geo &ag, double lin_a,
-                             int gate_a, double *ra0_out, double *ra1_out, int *err) {
+__device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
+                             int gate_a, double *ra0_out, double *ra1_out, int *n_stash, int *err) {
+#ifdef MPP_PROFILE
+  unsigned long long dpt_ = clock64();
+#endif
   const DevParams *P = c.P;
   const Lds &L = c.L;
   const int np = P->model.n_pair;
   const bool has_rem = rem >= 0;
-  unsigned short *cand = L.cand + (size_t)c.wave * CAND_MAX;
-  Geo gr;
+  Geo2 gr;
   Rect rr;
   if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
   else { gr = ag; rr = ar; }
   int cir = 0, cjr = 0, cia = 0, cja = 0;
-  if (has_rem) cell_index(P, gr.x, gr.y, &cir, &cjr);
-  if (has_add) cell_index(P, ag.x, ag.y, &cia, &cja);
+  if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
+  if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
 
-  // ---- gather candidate slots from the 3x3 cells around the removed and the added point
+  // ---- the 3x3 cells around the removed and the added point: lanes 0..17 own one cell each
   int my_cell = -1;
   if (c.lane < 18) {
     bool second = c.lane >= 9;
@@ -206,143 +276,188 @@ __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &
     if (ok && i >= 0 && i < P->nx && j >= 0 && j < P->ny) my_cell = j + i * P->ny;
   }
   int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
-  int incl = my_cnt;
+  // offsets of the 18 cells in the flattened candidate index space (wave-uniform, scalar registers)
+  int M = 0;
+  int my_lo = 0, my_base = 0;           // per lane j: first flattened index of its cell, LDS base of that cell
+  {
+    int lo = 0;
 #pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    int tmp = __shfl_up(incl, o, WAVE);
-    if (c.lane >= o) incl += tmp;
+    for (int k = 0; k < 18; ++k) {
+      int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
+      int cell_k = __builtin_amdgcn_readlane(my_cell, k);
+      if (c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+      lo += cnt_k;
+    }
+    M = lo;
   }
-  int M = __shfl(incl, 31, WAVE);
-  if (M > CAND_MAX) { *err = ERR_CAND_OVERFLOW; M = CAND_MAX; }
-  int off = incl - my_cnt;
-  for (int e = 0; e < my_cnt && off + e < CAND_MAX; ++e) cand[off + e] = L.cell_items[my_cell * P->cell_cap + e];
-  wave_lds_fence();
 
-  double sum_de = 0.0, ra[2] = {0.0, 0.0};
+  DPROF(0);
+#ifdef MPP_PROFILE
+  if (c.wave == 0 && c.lane == 0) { atomicAdd(&g_prof2[9], (unsigned long long)M); atomicAdd(&g_prof2[11], 1ull); }
+#endif
+  double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
+  bool any_changed = false, any_a = false;
+  int stash_n = 0;
   for (int base = 0; base < M; base += WAVE) {
+    if (base > 0) {                              // (rare) more than 64 candidates: find this lane's cell again
+      int lo = 0;
+      my_lo = 0; my_base = 0;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
+        int cell_k = __builtin_amdgcn_readlane(my_cell, k);
+        if (base + c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+        lo += cnt_k;
+      }
+    }
     int j = base + c.lane;
     bool active = j < M;
-    int u = active ? (int)cand[j] : 0;
+    int u = active ? (int)L.cell_items[my_base + (j - my_lo)] : 0;
     if (active && u == rem) active = false;
-    Geo gu;
+    Geo2 gu;
     double oldv[2] = {0.0, 0.0}, newv[2] = {0.0, 0.0};
     bool slow[2] = {false, false};
     if (active) {
       gu = load_geo(L, u);
       oldv[0] = L.red0[u]; oldv[1] = L.red1[u];
-      double d_r = 0.0, d_a = 0.0;
-      if (has_rem) { double dx = (double)(gu.x - gr.x), dy = (double)(gu.y - gr.y); d_r = sqrt(dx * dx + dy * dy); }
-      if (has_add) { double dx = (double)(gu.x - ag.x), dy = (double)(gu.y - ag.y); d_a = sqrt(dx * dx + dy * dy); }
+      int d2r = 0, d2a = 0;
+      if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
+      if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
       for (int p = 0; p < np; ++p) {
         const mpp_pair_term &pt = P->model.pair[p];
-        bool in_r = has_rem && d_r <= pt.max_dist, in_a = has_add && d_a <= pt.max_dist;
+        bool in_r = has_rem && d2r <= P->maxd2[p], in_a = has_add && d2a <= P->maxd2[p];
         double nv = oldv[p];
         if (in_r && oldv[p] != 0.0) {
-          bool uf = slot_first(L, u, gu, rr.x, rr.y, rr.s, rr.r, rr.a);
-          double v_r = pair_value(pt, gu, gr, uf, d_r);
+          bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
+          double v_r = pair_value(pt, gu, gr, uf, d2r);
           if (v_r == oldv[p]) slow[p] = true;       // the removed point carries u's extremum
         }
         if (in_a) {
-          bool uf = slot_first(L, u, gu, ar.x, ar.y, ar.s, ar.r, ar.a);
-          double v_a = pair_value(pt, gu, ag, uf, d_a);
+          bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+          double v_a = pair_value(pt, gu, ag, uf, d2a);
           ra[p] = reduce2(pt.reduce, ra[p], v_a);
           nv = reduce2(pt.reduce, nv, v_a);
+          any_a = true;
         }
         newv[p] = nv;
       }
     }
-    // cooperative re-scan for the lanes whose extremum goes away
-    for (int p = 0; p < np; ++p) {
-      unsigned long long mask = __ballot(slow[p]);
-      while (mask) {
-        int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        int ub = __shfl(u, src, WAVE);
-        double v = rescan_point(c, p, ub, rem, has_add, ar, ag);
-        if (c.lane == src) newv[p] = v;
+    DPROF(1);
+    // the neighbours that lose their extremum are re-reduced over their own 3x3 cells
+    for (int p = 0; p < np; ++p)
+      if (slow[p]) newv[p] = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+    DPROF(2);
+    bool changed = active && ((newv[0] != oldv[0]) || (newv[1] != oldv[1]));
+    if (changed) {
+      double lin = L.lin[u];
+      int gt = L.gate[u];
+      de_acc += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
+                finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
+      any_changed = true;
+      if (APPLY) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
+    }
+    unsigned long long cm = __ballot(changed);
+    if (!APPLY && changed) {
+      int rank = stash_n + __popcll(cm & ((1ull << c.lane) - 1ull));
+      if (rank < STASH) {
+        L.stash_slot[c.wave * STASH + rank] = (unsigned short)u;
+        L.stash_v0[c.wave * STASH + rank] = newv[0];
+        L.stash_v1[c.wave * STASH + rank] = newv[1];
       }
     }
-    if (active) {
-      bool changed = false;
-      for (int p = 0; p < np; ++p) changed |= (newv[p] != oldv[p]);
-      if (changed) {
-        double lin = L.lin[u];
-        int gt = L.gate[u];
-        sum_de += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
-                  finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
-        if (APPLY) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
-      }
-    }
+    stash_n += __popcll(cm);
   }
-  sum_de = wave_sum(sum_de);
-  double ra0 = np > 0 ? wave_reduce(P->model.pair[0].reduce, ra[0]) : 0.0;
-  double ra1 = np > 1 ? wave_reduce(P->model.pair[1].reduce, ra[1]) : 0.0;
+  DPROF(3);
+  // combine the few lanes that contribute, in ascending lane order (deterministic, wave-uniform result)
+  double sum_de = 0.0, ra0 = 0.0, ra1 = 0.0;
+  unsigned long long cm = __ballot(any_changed);
+  while (cm) {
+    int src = __ffsll((long long)cm) - 1;
+    cm &= cm - 1;
+    sum_de += readlane_d(de_acc, src);
+  }
+  unsigned long long am = __ballot(any_a);
+  while (am) {
+    int src = __ffsll((long long)am) - 1;
+    am &= am - 1;
+    if (np > 0) ra0 = reduce2(P->model.pair[0].reduce, ra0, readlane_d(ra[0], src));
+    if (np > 1) ra1 = reduce2(P->model.pair[1].reduce, ra1, readlane_d(ra[1], src));
+  }
   *ra0_out = ra0; *ra1_out = ra1;
+  *n_stash = stash_n;
+  (void)err;
   double dE = sum_de;
   if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra0, ra1));
   if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  DPROF(4);
   return dE;
 }
 
 // ---- proposal densities (shape_samplers.py:103-108, transform_kernels.py:94-99, :203-225) -------
-__device__ double wave_incl_scan(double v, int lane) {
+// One 32-bin mark row (128 B): every lane reads the whole row (a broadcast read of one cache line) and
+// sums it in index order -- no cross-lane traffic, wave-uniform result, same order as the oracle.
+// Returns P[cls]/sum; with `draw` the class is first drawn: #{j : cumsum_j <= u*sum}.
+__device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool draw, double u, int *drawn) {
+  const float4 *row = (const float4 *)mark_row(c.P, c.t, k, x, y);
+  float4 q[8];
 #pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    double tmp = __shfl_up(v, o, WAVE);
-    if (lane >= o) v += tmp;
+  for (int i = 0; i < 8; ++i) q[i] = row[i];
+  double v[MPP_NCLASS];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[4 * i] = q[i].x; v[4 * i + 1] = q[i].y; v[4 * i + 2] = q[i].z; v[4 * i + 3] = q[i].w; }
+  double tot = 0.0;
+#pragma unroll
+  for (int i = 0; i < MPP_NCLASS; ++i) tot += v[i];
+  if (draw) {
+    double acc = 0.0, thr = u * tot;
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) { acc += v[i]; d += (acc <= thr) ? 1 : 0; }
+    cls = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
+    *drawn = cls;
   }
-  return v;
-}
-// normalised probability of class `cls` in the 32-bin row, and (optionally) a class drawn with u
-__device__ double row_prob(const Chain &c, int k, int x, int y, int cls, double u, int *drawn) {
-  const float *row = mark_row(c.P, c.t, k, x, y);
-  double v = c.lane < MPP_NCLASS ? (double)row[c.lane] : 0.0;       // one coalesced 128-B read
-  double acc = wave_incl_scan(v, c.lane);
-  double tot = __shfl(acc, WAVE - 1, WAVE);
-  if (drawn) {
-    unsigned long long m = __ballot(c.lane < MPP_NCLASS && acc / tot <= u);
-    int d = __popcll(m);
-    *drawn = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
-    cls = *drawn;
-  }
-  return __shfl(v, cls, WAVE) / tot;
+  double pc = 0.0;
+#pragma unroll
+  for (int i = 0; i < MPP_NCLASS; ++i) pc = (i == cls) ? v[i] : pc;
+  return pc / tot;
 }
 __device__ double birth_density(const Chain &c, const Rect &q) {
   const DevParams *P = c.P;
   double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / c.t.rowbase[P->H];
-  for (int k = 0; k < 3; ++k) d *= row_prob(c, k, q.x, q.y, value_to_class(P, k, mark_of(q, k)), 0.0, nullptr);
+  d *= row_prob(c, 0, q.x, q.y, value_to_class_tab(P, c.L.edges, 0, q.s), false, 0.0, nullptr);
+  d *= row_prob(c, 1, q.x, q.y, value_to_class_tab(P, c.L.edges + MPP_NCLASS, 1, q.r), false, 0.0, nullptr);
+  d *= row_prob(c, 2, q.x, q.y, value_to_class_tab(P, c.L.edges + 2 * MPP_NCLASS, 2, q.a), false, 0.0, nullptr);
   return d * ((double)P->H * (double)P->W * 32768.0);
 }
-// window of the data-driven translation around (x,y): sum of det, optional draw of an element
-__device__ double window_sum(const Chain &c, int x, int y, bool draw, double u, int *ex, int *ey) {
+// data-driven translation (transform_kernels.py:77-89): draw a pixel of the (2*max_delta+1)^2 window
+// around (x,y) with probability det/sum.  Lane i owns window row i (<= 31 rows): its segment sum comes
+// from the per-row prefix table, the row is found by an ordered readlane walk, the column by a ballot.
+__device__ void window_draw(const Chain &c, int x, int y, double u, int *ex, int *ey) {
   const DevParams *P = c.P;
-  int md = P->kern.max_delta;
-  int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
-  int wc = y1 - y0, cnt = (x1 - x0) * wc;
-  int per = (cnt + WAVE - 1) / WAVE;                      // consecutive elements per lane (row-major order)
-  double loc[8];
-  double run = 0.0;
-  for (int i = 0; i < per && i < 8; ++i) {
-    int e = c.lane * per + i;
-    double v = e < cnt ? (double)c.t.det[(size_t)(x0 + e / wc) * P->W + (y0 + e % wc)] : 0.0;
-    run += v; loc[i] = run;
+  const int md = P->kern.max_delta;
+  const int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
+  const int nrow = x1 - x0, wc = y1 - y0;
+  const double tot = c.t.boxsum[(size_t)x * P->W + y];
+  double seg = 0.0;
+  if (c.lane < nrow) {
+    const double *rp = c.t.rowpart + (size_t)(x0 + c.lane) * P->W;
+    seg = rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0);
   }
-  double incl = wave_incl_scan(run, c.lane);
-  double tot = __shfl(incl, WAVE - 1, WAVE);
-  if (draw) {
-    double before = incl - run;
-    int k = 0;
-    for (int i = 0; i < per && i < 8; ++i) {
-      int e = c.lane * per + i;
-      if (e < cnt && (before + loc[i]) / tot <= u) ++k;
-    }
-    int e = wave_sum_i(k);
-    if (e >= cnt) e = cnt - 1;
-    *ex = x0 + e / wc; *ey = y0 + e % wc;
+  double before = 0.0;          // sum of the rows above the chosen one
+  int row = 0;
+  for (int i = 0; i < nrow; ++i) {
+    double nxt = before + readlane_d(seg, i);
+    if (nxt / tot <= u && i < nrow - 1) { before = nxt; row = i + 1; } else break;
   }
-  return tot;
+  const double *rp = c.t.rowpart + (size_t)(x0 + row) * P->W;
+  const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
+  bool le = false;
+  if (c.lane < wc) le = (before + (rp[y0 + c.lane] - lead)) / tot <= u;
+  int col = __popcll(__ballot(le));
+  if (col >= wc) col = wc - 1;
+  *ex = x0 + row; *ey = y0 + col;
 }
-__device__ double normal_pdf(double x, double sigma) {
+__device__ __forceinline__ double normal_pdf(double x, double sigma) {
   return exp(-(x * x) / (2.0 * sigma * sigma)) / (sigma * sqrt(MPP_TWO_PI));
 }
 __device__ void box_muller(uint32_t a, uint32_t b, double *z0, double *z1) {
@@ -360,8 +475,12 @@ __device__ double wrap_mark(const DevParams *P, int k, double v) {
   return v < lo ? lo : (v > hi ? hi : v);
 }
 
+// which parts of the target's cached geometry survive the proposal
+#define KEEP_TRIG 1
+#define KEEP_SIZE 2
+
 // draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
-__device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &r) {
+__device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &r, int *keep) {
   const DevParams *P = c.P;
   double uk = u53(w[0], w[1]);
   int k = 0;
@@ -369,6 +488,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1;
   r.aux0 = r.aux1 = 0.0; r.ax = r.ay = 0; r.as = r.ar = r.aa = 0.0; r.rx = r.ry = 0;
   r.u_acc = u53(w[10], w[11]);
+  *keep = 0;
   if (k == MPP_K_UBIRTH) {
     r.has_add = 1;
     r.ax = (int)mulhi32(w[3], (uint32_t)P->H); r.ay = (int)mulhi32(w[4], (uint32_t)P->W);
@@ -379,22 +499,26 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   }
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
-    double u = u53(w[3], w[4]), tot = c.t.rowbase[P->H];
-    int cnt = 0;
-    for (int i = c.lane; i < P->H; i += WAVE) cnt += (c.t.rowbase[i + 1] / tot <= u) ? 1 : 0;
-    int row = wave_sum_i(cnt);
+    const double u = u53(w[3], w[4]), tot = c.t.rowbase[P->H];
+    int row = 0;                                      // #rows whose inclusive cdf is <= u (monotone: ballots)
+    for (int i0 = 0; i0 < P->H; i0 += WAVE) {
+      int i = i0 + c.lane;
+      row += __popcll(__ballot(i < P->H && c.t.rowbase[i + 1] / tot <= u));
+    }
     if (row >= P->H) row = P->H - 1;
-    double base = c.t.rowbase[row];
+    const double base = c.t.rowbase[row];
     const double *part = c.t.rowpart + (size_t)row * P->W;
-    cnt = 0;
-    for (int j = c.lane; j < P->W; j += WAVE) cnt += ((base + part[j]) / tot <= u) ? 1 : 0;
-    int col = wave_sum_i(cnt);
+    int col = 0;
+    for (int j0 = 0; j0 < P->W; j0 += WAVE) {
+      int j = j0 + c.lane;
+      col += __popcll(__ballot(j < P->W && (base + part[j]) / tot <= u));
+    }
     if (col >= P->W) col = P->W - 1;
     r.ax = row; r.ay = col;
     int cls;
-    row_prob(c, 0, row, col, 0, u32d(w[5]), &cls); r.as = P->maps.edges[0][cls];
-    row_prob(c, 1, row, col, 0, u32d(w[6]), &cls); r.ar = P->maps.edges[1][cls];
-    row_prob(c, 2, row, col, 0, u32d(w[7]), &cls); r.aa = P->maps.edges[2][cls];
+    row_prob(c, 0, row, col, 0, true, u32d(w[5]), &cls); r.as = c.L.edges[cls];
+    row_prob(c, 1, row, col, 0, true, u32d(w[6]), &cls); r.ar = c.L.edges[MPP_NCLASS + cls];
+    row_prob(c, 2, row, col, 0, true, u32d(w[7]), &cls); r.aa = c.L.edges[2 * MPP_NCLASS + cls];
     return;
   }
   if (n == 0) return;
@@ -412,10 +536,12 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     int nx = (int)((double)q.x + d0), ny = (int)((double)q.y + d1);
     q.x = min(max(nx, 0), P->H - 1); q.y = min(max(ny, 0), P->W - 1);
     r.aux0 = d0; r.aux1 = d1;
+    *keep = KEEP_TRIG | KEEP_SIZE;
   } else if (k == MPP_K_DTRANS) {
     int ex, ey;
-    window_sum(c, q.x, q.y, true, u53(w[3], w[4]), &ex, &ey);
+    window_draw(c, q.x, q.y, u53(w[3], w[4]), &ex, &ey);
     q.x = ex; q.y = ey;
+    *keep = KEEP_TRIG | KEEP_SIZE;
   } else if (k == MPP_K_GTRANSF) {
     int pid = (int)mulhi32(w[3], 3u);
     double z0, z1;
@@ -423,17 +549,20 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     double d = P->kern.sigma_transform * (P->maps.vmax[pid] - P->maps.vmin[pid]) * z0;
     set_mark(q, pid, wrap_mark(P, pid, mark_of(q, pid) + d));
     r.pid = pid; r.aux0 = d;
+    *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
   } else {
     int pid = (int)mulhi32(w[3], 3u), cls;
-    row_prob(c, pid, q.x, q.y, 0, u32d(w[4]), &cls);
-    set_mark(q, pid, P->maps.edges[pid][cls]);
+    row_prob(c, pid, q.x, q.y, 0, true, u32d(w[4]), &cls);
+    set_mark(q, pid, c.L.edges[pid * MPP_NCLASS + cls]);
     r.pid = pid; r.ncls = cls;
+    *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
   }
   r.ax = q.x; r.ay = q.y; r.as = q.s; r.ar = q.r; r.aa = q.a;
 }
 
-// n-independent parts of the forward / backward proposal probabilities
-__device__ void proposal_densities(const Chain &c, Rec &r) {
+// n-independent parts of the forward / backward proposal probabilities.  The symmetric Gaussian
+// kernels have qf == qb, which cancels in the Green ratio: their pdf is evaluated only for traces.
+__device__ void proposal_densities(const Chain &c, Rec &r, bool tracing) {
   const DevParams *P = c.P;
   r.qf = 1.0; r.qb = 1.0;
   Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
@@ -443,23 +572,29 @@ __device__ void proposal_densities(const Chain &c, Rec &r) {
       if (r.has_rem) r.qb = birth_density(c, load_rect(c.L, r.tslot));
       break;
     case MPP_K_GTRANS:
-      if (r.has_rem) r.qf = r.qb = normal_pdf(r.aux0, P->kern.sigma_trans) * normal_pdf(r.aux1, P->kern.sigma_trans);
+      if (r.has_rem && tracing)
+        r.qf = r.qb = normal_pdf(r.aux0, P->kern.sigma_trans) * normal_pdf(r.aux1, P->kern.sigma_trans);
       break;
     case MPP_K_DTRANS:
-      if (r.has_rem) {
-        r.qf = (double)c.t.det[(size_t)r.ax * P->W + r.ay] / window_sum(c, r.rx, r.ry, false, 0.0, nullptr, nullptr);
-        r.qb = (double)c.t.det[(size_t)r.rx * P->W + r.ry] / window_sum(c, r.ax, r.ay, false, 0.0, nullptr, nullptr);
+      if (r.has_rem) {        // transform_kernels.py:94-99: window renormalised around start resp. end
+        r.qf = (double)c.t.det[(size_t)r.ax * P->W + r.ay] / c.t.boxsum[(size_t)r.rx * P->W + r.ry];
+        r.qb = (double)c.t.det[(size_t)r.rx * P->W + r.ry] / c.t.boxsum[(size_t)r.ax * P->W + r.ay];
       }
       break;
     case MPP_K_GTRANSF:
-      if (r.has_rem)
+      if (r.has_rem && tracing)
         r.qf = r.qb = normal_pdf(r.aux0, P->kern.sigma_transform * (P->maps.vmax[r.pid] - P->maps.vmin[r.pid]));
       break;
     case MPP_K_DTRANSF:
       if (r.has_rem) {
         Rect old = load_rect(c.L, r.tslot);
-        r.qf = row_prob(c, r.pid, old.x, old.y, r.ncls, 0.0, nullptr);
-        r.qb = row_prob(c, r.pid, old.x, old.y, value_to_class(P, r.pid, mark_of(old, r.pid)), 0.0, nullptr);
+        int oc = value_to_class_tab(P, c.L.edges + r.pid * MPP_NCLASS, r.pid, mark_of(old, r.pid));
+        const float *row = mark_row(P, c.t, r.pid, old.x, old.y);
+        // both classes of the same row: P[new]/sum and P[old]/sum (one row read)
+        double tot = 0.0;
+        for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)row[i];
+        r.qf = (double)row[r.ncls] / tot;
+        r.qb = (double)row[oc] / tot;
       }
       break;
     default: break;
@@ -506,15 +641,63 @@ __device__ void cell_insert(const Chain &c, int cell, int slot, int *err) {
   }
   wave_lds_fence();
 }
-__device__ void write_slot(const Chain &c, int slot, const Rect &q, const Geo &g, double lin, int gate, double r0,
-                           double r1) {
+__device__ void write_slot(const Chain &c, int slot, const Rec &q) {
   const Lds &L = c.L;
   if (c.lane == 0) {
-    L.xy[slot] = (q.x & 0xffff) | (q.y << 16);
-    L.s[slot] = q.s; L.r[slot] = q.r; L.a[slot] = q.a;
-    L.ca[slot] = g.ca; L.sa[slot] = g.sa; L.hl[slot] = g.hl; L.hw[slot] = g.hw;
-    L.lin[slot] = lin; L.gate[slot] = (unsigned char)gate; L.red0[slot] = r0; L.red1[slot] = r1;
+    L.xy[slot] = (q.ax & 0xffff) | (q.ay << 16);
+    L.s[slot] = q.as; L.r[slot] = q.ar; L.a[slot] = q.aa;
+    L.ca[slot] = q.ca; L.sa[slot] = q.sa; L.hl[slot] = q.hl; L.hw[slot] = q.hw; L.rad[slot] = q.rad;
+    L.lin[slot] = q.lin_a; L.gate[slot] = (unsigned char)q.gate_a; L.red0[slot] = q.ra0; L.red1[slot] = q.ra1;
   }
+}
+
+// evaluate one step completely (everything but the state mutation): proposal geometry, unit energy,
+// dE, and the accept decision for population n at temperature T
+#ifdef MPP_PROFILE
+#define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
+__device__ void evaluate(const Chain &c, Rec &r, int keep, int n, double T, bool tracing, int *err,
+                         unsigned long long *prof) {
+  unsigned long long pt_ = clock64();
+#else
+#define EPROF(i)
+__device__ void evaluate(const Chain &c, Rec &r, int keep, int n, double T, bool tracing, int *err) {
+#endif
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  proposal_densities(c, r, tracing);
+  EPROF(4);
+  r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
+  r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
+  if (r.has_rem || r.has_add) {
+    Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
+    Geo2 ag;
+    ag.g.x = add.x; ag.g.y = add.y; ag.g.hl = ag.g.hw = ag.g.ca = ag.g.sa = 0.0; ag.rad = 0.0;
+    if (r.has_add) {
+      if (keep & KEEP_SIZE) { ag.g.hl = L.hl[r.tslot]; ag.g.hw = L.hw[r.tslot]; ag.rad = L.rad[r.tslot]; }
+      else {
+        double length = (2.0 * add.s) / (1.0 + add.r), width = add.r * length;
+        ag.g.hl = length / 2.0; ag.g.hw = width / 2.0;
+        ag.rad = geo_radius(ag.g);
+      }
+      if (keep & KEEP_TRIG) { ag.g.ca = L.ca[r.tslot]; ag.g.sa = L.sa[r.tslot]; }
+      else { double al = add.a + MPP_PI / 2.0; ag.g.ca = cos(al); ag.g.sa = sin(al); }
+      EPROF(5);
+      unit_part(P, c.t, L.edges, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
+      r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;
+      EPROF(6);
+    }
+    r.dE = eval_delta<false>(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+                             &r.n_stash, err);
+    EPROF(7);
+  }
+  double fwd, bwd;
+  green_terms(P, r, n, c.t.intensity, &fwd, &bwd);
+  // rjmcmc.py:105-113: accept <=> log(u+eps) < -dE/T + log(bwd+eps) - log(fwd+eps)
+  //                           <=> u+eps < exp(-dE/T) * (bwd+eps)/(fwd+eps)      (one exp instead of three logs)
+  double ratio = (bwd + EPS_GREEN) / (fwd + EPS_GREEN);
+  r.accepted = (r.u_acc + EPS_GREEN) < exp(-r.dE / T) * ratio ? 1 : 0;
+  if (tracing) { r.fwd = fwd; r.bwd = bwd; r.log_alpha = (-r.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN); }
+  EPROF(8);
 }
 
 template <int SPEC>
@@ -530,24 +713,27 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
   const int ncell = P->nx * P->ny, cap = P->cap;
   c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC);
   c.lane = threadIdx.x & (WAVE - 1);
-  c.wave = threadIdx.x / WAVE;
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // wave-uniform: lets Philox etc. run on the scalar unit
   const Lds &L = c.L;
   const int tid = threadIdx.x, nthr = WAVE * SPEC;
   const bool tracing = (out != nullptr || props != nullptr) && tile == trace_tile;
 
   // ---------------------------------------------------------------- load the configuration
-  int n0 = *c.t.n;
-  int err = *c.t.err;
+  int n0 = __builtin_amdgcn_readfirstlane(*c.t.n);
+  int err = __builtin_amdgcn_readfirstlane(*c.t.err);
   if (n0 > cap) { n0 = cap; err = ERR_POINT_OVERFLOW; }
+  for (int i = tid; i < 3 * MPP_NCLASS; i += nthr) L.edges[i] = P->maps.edges[i / MPP_NCLASS][i % MPP_NCLASS];
   for (int i = tid; i < cap; i += nthr) L.order[i] = (unsigned short)i;
   for (int i = tid; i < ncell; i += nthr) L.cell_cnt[i] = 0;
+  __syncthreads();
   for (int i = tid; i < n0; i += nthr) {
     Rect q{c.t.px[i], c.t.py[i], c.t.ps[i], c.t.pr[i], c.t.pa[i]};
     Geo g = make_geo(q);
     double lin; int gate;
-    unit_part(P, c.t, q, g, &lin, &gate, nullptr);
+    unit_part(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
     L.xy[i] = (q.x & 0xffff) | (q.y << 16);
     L.s[i] = q.s; L.r[i] = q.r; L.a[i] = q.a; L.ca[i] = g.ca; L.sa[i] = g.sa; L.hl[i] = g.hl; L.hw[i] = g.hw;
+    L.rad[i] = geo_radius(g);
     L.lin[i] = lin; L.gate[i] = (unsigned char)gate; L.red0[i] = 0.0; L.red1[i] = 0.0;
   }
   __syncthreads();
@@ -561,12 +747,14 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
       L.cell_cnt[cell] = (unsigned short)(cnt + 1);
     }
     L.sh[0] = n0; L.sh[1] = err; L.sh[2] = 0;
+    *(double *)(L.sh + 4) = *c.t.T;
   }
   __syncthreads();
   err = L.sh[1];
   {
     Rect dummy{0, 0, 0, 0, 0};
-    Geo dg{0, 0, 0, 0, 0, 0};
+    Geo2 dg;
+    dg.g = Geo{0, 0, 0, 0, 0, 0}; dg.rad = 0.0;
     for (int u = c.wave; u < n0; u += SPEC)
       for (int p = 0; p < P->model.n_pair; ++p) {
         double v = rescan_point(c, p, u, -1, false, dummy, dg);
@@ -576,31 +764,35 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
   __syncthreads();
 
   // ---------------------------------------------------------------- the chain
-  double T = *c.t.T;                                          // wave 0 keeps the authoritative copy
   const double alpha = c.t.T[1], T_target = c.t.T[2];
   long long step0 = *c.t.step, done = 0;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-
 #ifdef MPP_PROFILE
   unsigned long long prof_[16] = {0};
 #endif
+
   while (done < n_steps && err == 0) {
-    const int n = L.sh[0];
+    const int n = __builtin_amdgcn_readfirstlane(L.sh[0]);
+    double T = *(double *)(L.sh + 4);
     PROF_T0();
-    // ---- phase A: wave w evaluates step done+w against the current state
+    // ---- phase A: wave w evaluates step done+w against the current state, assuming that the
+    //      steps before it in this round change nothing it depends on
     const long long my = done + c.wave;
     Rec r;
-    r.valid = 0;
+    r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0;
     if (my < n_steps) {
+      for (int i = 0; i < c.wave; ++i) if (T > T_target) T *= alpha;      // temperature of step `my`
       r.valid = 1;
+      int keep = 0;
       if (tape) {
         const mpp_proposal &tp = tape[my];
-        r.kernel = tp.kernel; r.tidx = tp.target; r.tslot = -1; r.has_rem = 0; r.has_add = 0;
+        r.kernel = tp.kernel; r.tidx = tp.target; r.tslot = -1;
         r.ax = tp.ax; r.ay = tp.ay; r.as = tp.as; r.ar = tp.ar; r.aa = tp.aa; r.aux0 = tp.aux0; r.aux1 = tp.aux1;
         r.pid = tp.param_id; r.ncls = tp.new_class; r.u_acc = tp.u_accept; r.rx = r.ry = 0;
         bool is_birth = tp.kernel == MPP_K_UBIRTH || tp.kernel == MPP_K_DBIRTH;
         bool is_death = tp.kernel == MPP_K_UDEATH || tp.kernel == MPP_K_DDEATH;
-        if (is_birth) r.has_add = 1;
+        if (tp.kernel < 0 || tp.kernel >= MPP_NKERNEL) { r.valid = 0; r.kernel = -1; }
+        else if (is_birth) r.has_add = 1;
         else if (n > 0 && tp.target >= 0) {
           if (tp.target >= n) { r.valid = 0; r.kernel = -1; }       // reported at commit time
           else {
@@ -610,34 +802,29 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
             r.rx = xy & 0xffff; r.ry = (xy >> 16) & 0xffff;
           }
         }
+        if (r.valid && (tp.kernel == MPP_K_DTRANSF || tp.kernel == MPP_K_GTRANSF) && r.has_rem &&
+            (tp.param_id < 0 || tp.param_id > 2 || (tp.kernel == MPP_K_DTRANSF && (tp.new_class < 0 || tp.new_class >= MPP_NCLASS)))) {
+          r.valid = 0; r.kernel = -1;
+        }
       } else {
         uint32_t w[12];
         uint64_t s = (uint64_t)(step0 + my);
         for (uint32_t b = 0; b < 3; ++b)
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
-        draw_proposal(c, w, n, r);
+        draw_proposal(c, w, n, r, &keep);
       }
       PROF_ADD(0);
+      if (r.valid && r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
       if (r.valid) {
-        if (r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
+        int e2 = 0;
+#ifdef MPP_PROFILE
+        evaluate(c, r, keep, n, T, tracing, &e2, prof_);
+#else
+        evaluate(c, r, keep, n, T, tracing, &e2);
+#endif
+        if (e2) { r.valid = 0; r.kernel = -2 - e2; }
       }
-      if (r.valid) {
-        proposal_densities(c, r);
-        PROF_ADD(1);
-        r.dE = 0.0;
-        if (r.has_rem || r.has_add) {
-          Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
-          Geo ag = make_geo(add);
-          double lin_a = 0.0; int gate_a = 1;
-          if (r.has_add) unit_part(P, c.t, add, ag, &lin_a, &gate_a, nullptr);
-          PROF_ADD(2);
-          double ra0, ra1;
-          int e2 = 0;
-          r.dE = eval_delta<false>(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, lin_a, gate_a, &ra0, &ra1, &e2);
-          if (e2) { r.valid = 0; r.kernel = -2 - e2; }
-          PROF_ADD(3);
-        }
-      }
+      PROF_ADD(1);
     }
     if (SPEC > 1) {
       if (c.lane == 0) L.rec[c.wave] = r;
@@ -646,35 +833,37 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
     // ---- phase B: wave 0 commits in order
     if (c.wave == 0) {
       int committed = 0, cur_n = n;
+      double Tc = *(double *)(L.sh + 4);
       bool stop = false;
       for (int w = 0; w < SPEC && !stop; ++w) {
-        Rec q = (SPEC > 1) ? L.rec[w] : r;
         if (done + w >= n_steps) break;
+        Rec q = (SPEC > 1) ? L.rec[w] : r;
         if (!q.valid) {
           if (q.kernel == -1) err = ERR_BAD_TARGET;
           else if (q.kernel <= -3) err = -2 - q.kernel;
-          // otherwise: invalidated by an earlier accept of this round -> re-evaluate next round
+          // otherwise: invalidated by an earlier accept of this round -> re-evaluated next round
           break;
         }
-        double fwd, bwd;
-        green_terms(P, q, cur_n, c.t.intensity, &fwd, &bwd);
-        double log_alpha = (-q.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN);
-        int accepted = log(q.u_acc + EPS_GREEN) < log_alpha ? 1 : 0;
-        PROF_ADD(4);
-        if (accepted && (q.has_rem || q.has_add)) {
-          Rect add{q.ax, q.ay, q.as, q.ar, q.aa};
-          Geo ag = make_geo(add);
-          double lin_a = 0.0; int gate_a = 1;
-          if (q.has_add) unit_part(P, c.t, add, ag, &lin_a, &gate_a, nullptr);
-          double ra0, ra1;
-          int e2 = 0;
-          eval_delta<true>(c, q.has_rem ? q.tslot : -1, q.has_add != 0, add, ag, lin_a, gate_a, &ra0, &ra1, &e2);
+        if (q.accepted && (q.has_rem || q.has_add)) {
+          if (q.n_stash > STASH) {
+            // more neighbours changed than the stash holds (dense clusters): redo the evaluation in place
+            Rect add{q.ax, q.ay, q.as, q.ar, q.aa};
+            Geo2 ag;
+            ag.g = Geo{q.ax, q.ay, q.hl, q.hw, q.ca, q.sa}; ag.rad = q.rad;
+            double ra0, ra1;
+            int ns, e2 = 0;
+            eval_delta<true>(c, q.has_rem ? q.tslot : -1, q.has_add != 0, add, ag, q.lin_a, q.gate_a, &ra0, &ra1, &ns, &e2);
+          } else if (c.lane < q.n_stash) {
+            int u = L.stash_slot[w * STASH + c.lane];
+            L.red0[u] = L.stash_v0[w * STASH + c.lane];
+            L.red1[u] = L.stash_v1[w * STASH + c.lane];
+          }
           wave_lds_fence();
           if (q.has_rem && q.has_add) {                      // move / transform: same slot
             int ci, cj;
             int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
             if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &err); }
-            write_slot(c, q.tslot, add, ag, lin_a, gate_a, ra0, ra1);
+            write_slot(c, q.tslot, q);
           } else if (q.has_rem) {                            // death: last index takes the hole
             int ci, cj;
             cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
@@ -689,7 +878,7 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
             else {
               int slot = L.order[cur_n], ci, cj;
               cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &err);
-              write_slot(c, slot, add, ag, lin_a, gate_a, ra0, ra1);
+              write_slot(c, slot, q);
               cur_n += 1;
             }
           }
@@ -697,32 +886,35 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
           // which later speculative steps are still trustworthy?
           if (SPEC > 1) {
             if (!(q.has_rem && q.has_add)) stop = true;      // n or the index->slot map changed
-            else
-              for (int w2 = w + 1; w2 < SPEC; ++w2) {
+            else {
+              // lane w2 judges record w2: it is stale if it touches the same slot or anything within
+              // 2*max_inter of the positions this step changed
+              int w2 = c.lane;
+              if (w2 > w && w2 < SPEC) {
                 Rec &o = L.rec[w2];
-                if (!o.valid) continue;
-                bool bad = o.has_rem && o.tslot == q.tslot;
-                const long long D2 = (long long)(4.0 * P->max_inter * P->max_inter) + 1;
-                int ox[2] = {o.rx, o.ax}, oy[2] = {o.ry, o.ay}, oh[2] = {o.has_rem, o.has_add};
-                int qx[2] = {q.rx, q.ax}, qy[2] = {q.ry, q.ay};
-                for (int a = 0; a < 2 && !bad; ++a)
-                  for (int b = 0; b < 2 && !bad; ++b)
-                    if (oh[a]) {
-                      long long dx = ox[a] - qx[b], dy = oy[a] - qy[b];
-                      if (dx * dx + dy * dy <= D2) bad = true;
-                    }
-                if (bad && c.lane == 0) o.valid = 0;
+                if (o.valid) {
+                  bool bad = o.has_rem && o.tslot == q.tslot;
+                  int ox[2] = {o.rx, o.ax}, oy[2] = {o.ry, o.ay}, oh[2] = {o.has_rem, o.has_add};
+                  int qx[2] = {q.rx, q.ax}, qy[2] = {q.ry, q.ay};
+                  for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b)
+                      if (oh[a]) {
+                        int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
+                        if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
+                      }
+                  if (bad) o.valid = 0;
+                }
               }
+            }
             wave_lds_fence();
           }
         }
-        PROF_ADD(5);
         if (tracing && c.lane == 0) {
           long long idx = done + w;
           if (out) {
             mpp_step_out so;
-            so.dE = q.dE; so.fwd = fwd; so.bwd = bwd; so.log_alpha = log_alpha; so.T = T; so.accepted = accepted;
-            so.n_after = cur_n;
+            so.dE = q.dE; so.fwd = q.fwd; so.bwd = q.bwd; so.log_alpha = q.log_alpha; so.T = Tc;
+            so.accepted = q.accepted; so.n_after = cur_n;
             out[idx] = so;
           }
           if (props) {
@@ -733,17 +925,18 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
             props[idx] = pp;
           }
         }
-        if (T > T_target) T *= alpha;                        // rjmcmc.py:158-159
+        if (Tc > T_target) Tc *= alpha;                      // rjmcmc.py:158-159
         committed += 1;
         if (err) break;
       }
-      if (c.lane == 0) { L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; }
+      if (c.lane == 0) { L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; *(double *)(L.sh + 4) = Tc; }
+      PROF_ADD(2);
     }
     __syncthreads();
-    err = L.sh[1];
-    done += L.sh[2];
+    err = __builtin_amdgcn_readfirstlane(L.sh[1]);
+    done += __builtin_amdgcn_readfirstlane(L.sh[2]);
     if (SPEC > 1) __syncthreads();
-    PROF_ADD(6);
+    PROF_ADD(3);
   }
 #ifdef MPP_PROFILE
   if (tid == 0) for (int i = 0; i < 16; ++i) g_prof[i] = prof_[i];
@@ -758,13 +951,19 @@ __global__ __launch_bounds__(WAVE *SPEC) void mpp_chain_kernel(const DevParams *
   }
   if (tid == 0) {
     *c.t.n = n_end; *c.t.err = err; *c.t.step = step0 + done;
-    *c.t.T = T;
+    *c.t.T = *(double *)(L.sh + 4);
   }
 }
 
 #ifdef MPP_PROFILE
 extern "C" void mpp_debug_read_prof(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+}
+extern "C" void mpp_debug_read_prof2(unsigned long long *out, int reset) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof2), sizeof(unsigned long long) * 16);
+  (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_clip_count), sizeof(unsigned long long));
+  if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof z);
+               (void)hipMemcpyToSymbol(HIP_SYMBOL(g_clip_count), z, sizeof(unsigned long long)); }
 }
 #endif
 
