@@ -115,7 +115,9 @@ const char *mpp_last_error(mpp_ctx *ctx);
 int mpp_set_stream(mpp_ctx *ctx, void *hip_stream);
 int mpp_synchronize(mpp_ctx *ctx);
 /* "spec_waves": proposals evaluated speculatively per round (1 = strictly one at a time; results
- * are identical for every value), "point_capacity": slots per tile, "cell_capacity" */
+ * are identical for every value), "point_capacity": slots per tile, "cell_capacity" (points per
+ * 32-px cell), "force_accept": apply every proposal without the Metropolis test (the kernel random
+ * walks of models/mpp/perturbation_sampler.py:152-169) */
 int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);
 int64_t mpp_get_option(mpp_ctx *ctx, const char *name);
 

@@ -166,6 +166,8 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else if (!strcmp(name, "cell_capacity")) {
     if (v < 1 || v > 32) return fail(c, -1, "cell_capacity must be in 1..32");
     c->cell_cap = (int)v; c->params_dirty = true;
+  } else if (!strcmp(name, "force_accept")) {
+    c->hp.force_accept = v ? 1 : 0; c->params_dirty = true;
   } else return fail(c, -1, "unknown option %s", name);
   return 0;
 }
@@ -174,6 +176,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "spec_waves")) return c->spec;
   if (!strcmp(name, "point_capacity")) return c->cap;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
+  if (!strcmp(name, "force_accept")) return c->hp.force_accept;
   if (!strcmp(name, "lds_bytes")) {
     int ncell = c->hp.nx * c->hp.ny;
     return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, c->spec);

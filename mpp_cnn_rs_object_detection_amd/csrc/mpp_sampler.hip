@@ -695,7 +695,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int keep, int n, double T, bool
   // rjmcmc.py:105-113: accept <=> log(u+eps) < -dE/T + log(bwd+eps) - log(fwd+eps)
   //                           <=> u+eps < exp(-dE/T) * (bwd+eps)/(fwd+eps)      (one exp instead of three logs)
   double ratio = (bwd + EPS_GREEN) / (fwd + EPS_GREEN);
-  r.accepted = (r.u_acc + EPS_GREEN) < exp(-r.dE / T) * ratio ? 1 : 0;
+  r.accepted = (P->force_accept || (r.u_acc + EPS_GREEN) < exp(-r.dE / T) * ratio) ? 1 : 0;
   if (tracing) { r.fwd = fwd; r.bwd = bwd; r.log_alpha = (-r.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN); }
   EPROF(8);
 }

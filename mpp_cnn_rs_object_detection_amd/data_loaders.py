@@ -1,0 +1,141 @@
+"""Image + score-map loading, tiling and merging for MPP inference.
+
+Mirrors the reference's ``models/mpp/data_loaders.py:30-161, :305-314`` (``load_image_w_maps``,
+``crop_image_w_maps``, ``merge_patches``, ``labels_to_rectangles``) and the tiling rule of
+``models/mpp/mpp_model.py:231-248``.  Score maps come either from the reference's on-disk hand-off
+(``NNNN_results.pkl`` of posnet / shapenet) or straight from the two U-Nets on the GPU
+(``unet.ScoreMapNets``), in which case they never leave the device.
+"""
+from __future__ import annotations
+
+import io
+import logging
+import os
+import pickle
+from copy import copy
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import mappings as _mappings
+from .custom_types import ImageWMaps
+from .paths import get_dataset_base_path, get_inference_path
+from .point_set import EPointsSet
+from .shapes import Rectangle, wla_to_sra
+
+PARAM_NAMES = ["size", "ratio", "angle"]
+PATCH_SIZE = 256          # hard-coded in the reference, mpp_model.py:231
+
+
+class _CompatUnpickler(pickle.Unpickler):
+    """The reference pickles its own ``ValueMapping`` class inside shapenet results; map it onto ours."""
+
+    def find_class(self, module, name):
+        if name == "ValueMapping":
+            return _mappings.ValueMapping
+        return super().find_class(module, name)
+
+
+def _load_pickle(path: str):
+    with open(path, "rb") as f:
+        return _CompatUnpickler(io.BytesIO(f.read())).load()
+
+
+def labels_to_rectangles(labels: Dict, param_names: Sequence[str] = PARAM_NAMES) -> List[Rectangle]:
+    """(a, b, angle) annotations -> Rectangle(size, ratio, angle mod pi) (reference ``data_loaders.py:305-314``)."""
+    out = []
+    for c, p in zip(labels["centers"], labels["parameters"]):
+        s, r, a = wla_to_sra(p[0], p[1], p[2])
+        out.append(Rectangle(int(c[0]), int(c[1]), size=float(s), ratio=float(r), angle=float(a % np.pi)))
+    return out
+
+
+def load_image_w_maps(patch_id, dataset: str, subset: str, position_model: str, shape_model: str,
+                      nets=None) -> ImageWMaps:
+    """Reference ``data_loaders.py:30-71``.  With ``nets`` (a ``ScoreMapNets``) the maps are computed on the GPU
+    instead of being read from the inference pickles."""
+    from matplotlib import pyplot as plt
+    patch_id = int(patch_id)
+    base = os.path.join(get_dataset_base_path(), dataset, subset)
+    image = plt.imread(os.path.join(base, "images", f"{patch_id:04}.png"))[:, :, :3]
+    labels = _load_pickle(os.path.join(base, "annotations", f"{patch_id:04}.pkl"))
+    if nets is not None:
+        det, marks = nets.infer(image)
+        maps = _mappings.default_mappings()
+    else:
+        pos = _load_pickle(os.path.join(get_inference_path(position_model, dataset, subset), f"{patch_id:04}_results.pkl"))
+        shp = _load_pickle(os.path.join(get_inference_path(shape_model, dataset, subset), f"{patch_id:04}_results.pkl"))
+        det = np.asarray(pos["detection_map"], dtype=np.float32)
+        marks = [np.ascontiguousarray(np.moveaxis(np.asarray(p)[0], 0, -1), dtype=np.float32) for p in shp["output"]]
+        maps = shp.get("mappings") or _mappings.default_mappings()
+    return ImageWMaps(image=image, name=f"{patch_id:04}", shape=tuple(image.shape[:2]), detection_map=det,
+                      param_dist_maps=marks, mappings=maps, param_names=PARAM_NAMES, labels=labels,
+                      gt_config=labels_to_rectangles(labels))
+
+
+def tile_anchors(shape, patch_size: int = PATCH_SIZE) -> List[np.ndarray]:
+    """Overlapping tiles covering the image: ``linspace(0, H - patch, ceil(H / patch))`` per axis
+    (reference ``mpp_model.py:233-240``)."""
+    H, W = shape[:2]
+    ax = np.linspace(0, H - patch_size, max(1, int(np.ceil(H / patch_size))), dtype=int)
+    ay = np.linspace(0, W - patch_size, max(1, int(np.ceil(W / patch_size))), dtype=int)
+    return [np.array([x, y]) for x in ax for y in ay]
+
+
+def crop_image_w_maps(image_data: ImageWMaps, tl_anchor: np.ndarray, patch_size: int) -> ImageWMaps:
+    """Reference ``data_loaders.py:74-119``; works on numpy arrays and on GPU tensors alike."""
+    x, y = int(tl_anchor[0]), int(tl_anchor[1])
+    sl = (slice(x, x + patch_size), slice(y, y + patch_size))
+    det = image_data.detection_map[sl]
+    marks = [m[sl] for m in image_data.param_dist_maps]
+    image = image_data.image[sl] if image_data.image is not None else None
+    shape = tuple(int(v) for v in det.shape[:2])
+    labels = image_data.labels
+    new_labels = None
+    if labels is not None and len(labels.get("centers", [])) > 0:
+        c = np.asarray(labels["centers"]) - np.array([x, y])
+        keep = np.all(c >= 0, axis=1) & np.all(c < np.array(shape), axis=1)
+        new_labels = {k: np.asarray(labels[k])[keep] for k in ("parameters", "categories", "difficult") if k in labels}
+        new_labels["centers"] = c[keep]
+    elif labels is not None:
+        new_labels = {k: np.asarray(v) for k, v in labels.items()}
+    gt = labels_to_rectangles(new_labels) if new_labels is not None and "parameters" in new_labels else []
+    return ImageWMaps(image=image, name=image_data.name, shape=shape, detection_map=det, param_dist_maps=marks,
+                      mappings=image_data.mappings, param_names=PARAM_NAMES, labels=new_labels, gt_config=gt,
+                      crop_data={"tl_anchor": np.array([x, y])})
+
+
+def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], original_image: ImageWMaps, energy_model,
+                  method: str, energy_setup, **kwargs):
+    """Reference ``data_loaders.py:122-161``: shift every tile's detections by its anchor, then (method
+    'distance') keep, among points closer than ``distance``, the one with the best Papangelou intensity
+    in the FULL aggregated configuration.  The intensities of all points come from one GPU launch."""
+    assert method in ["distance", "rjmcmc"]
+    unit, pair = energy_setup.make_energies(original_image)
+    merged: List[Rectangle] = []
+    for patch, result in zip(patches, results):
+        ax, ay = patch.crop_data["tl_anchor"]
+        for r in result:
+            q = copy(r)
+            q.x, q.y = int(q.x + ax), int(q.y + ay)
+            merged.append(q)
+    agg = EPointsSet(merged, original_image.shape, unit, pair, image_data=original_image,
+                     point_capacity=max(1024, len(merged) + 64))
+    if method == "distance" and len(merged) > 0:
+        distance = kwargs["distance"]
+        scores = agg.papangelou_all(energy_combinator=energy_model)
+        xy = np.array([[p.x, p.y] for p in merged], dtype=float)
+        removed = np.zeros(len(merged), dtype=bool)
+        for i in range(len(merged)):
+            if removed[i]:
+                continue
+            near = np.nonzero((np.hypot(xy[:, 0] - xy[i, 0], xy[:, 1] - xy[i, 1]) <= distance) & ~removed)[0]
+            if len(near) == 0:
+                continue
+            best = near[np.argmax(scores[near])]
+            removed[near] = True
+            removed[best] = False
+        logging.info(f"merge removing {int(removed.sum())} point(s)")
+        for i in np.nonzero(removed)[0]:
+            agg.remove(merged[i])
+    return agg

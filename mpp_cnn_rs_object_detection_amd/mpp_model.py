@@ -1,0 +1,236 @@
+"""``MPPModel``: config -> energy setup -> tiled RJMCMC inference -> merged, scored detections.
+
+Mirrors the reference's ``models/mpp/mpp_model.py:43-387`` for the inference path
+(``main.py -p infer -m mpp``): same config keys, same stored artefacts
+(``<model_path>/mpp/<name>/{config.json, calibration.json, energy_combination_model.*}``), same
+tiling / merge / scoring steps, same output files.  What changes is where the work runs: all
+tiles of an image are sampled in ONE kernel launch (one workgroup per tile) instead of a process
+pool, and with ``--gpus N`` (torchrun) tiles are dealt to ranks and the detections all-gathered.
+
+Weight learning (``train`` with ordering / integral criterion) and calibration are not part of
+this build; ``train`` supports the ``manual`` mode, which is what ``mpp_hrcM`` uses.
+"""
+from __future__ import annotations
+
+import json
+import logging
+import os
+import pickle
+import re
+import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import distributed as mdist
+from . import energies as E
+from .custom_types import ImageWMaps
+from .data_loaders import PATCH_SIZE, crop_image_w_maps, load_image_w_maps, merge_patches, tile_anchors
+from .dota_results import DOTAResultsTranslator
+from .paths import fetch_data_paths, get_inference_path, get_model_base_path
+from .sampler import TileBatchSampler, resolve_schedule
+from .shapes import Rectangle, rect_to_poly, sra_to_wla
+
+TRAIN_MODES = ["manual", "grad_descent", "integral_criterion", "ordering_criterion"]
+
+
+def load_energy_combinator(save_path: str):
+    """``energy_combination_model.json`` (this build) or, for models stored by the reference, its pickle
+    -- read with a restricted unpickler that only rebuilds the two combinator classes and numpy arrays."""
+    js = os.path.join(save_path, "energy_combination_model.json")
+    if os.path.exists(js):
+        with open(js) as f:
+            d = json.load(f)
+        if d["type"] == "LogisticEnergyCombinator":
+            return E.LogisticEnergyCombinator(weights=np.array(d["weights"], dtype=np.float32), bias=d["bias"],
+                                              energy_names=d["energy_names"])
+        if d["type"] == "HierarchicalEnergyCombinator":
+            return E.HierarchicalEnergyCombinator(np.array(d["weights_data"]), np.array(d["weights_prior"]),
+                                                  np.array(d["data_prior_weights"]), d["detection_threshold"],
+                                                  d.get("bias", 0.0))
+        if d["type"] == "ManualHierarchicalEnergyCombinator":
+            return E.ManualHierarchicalEnergyCombinator(d["weights_dict"], d["indicator_energy"],
+                                                        d.get("detection_threshold", 0.0))
+        raise ValueError(f"unknown combinator type {d['type']}")
+    pk = os.path.join(save_path, "energy_combination_model.pkl")
+    if os.path.exists(pk):
+        allowed = {"HierarchicalEnergyCombinator": E.HierarchicalEnergyCombinator,
+                   "LogisticEnergyCombinator": E.LogisticEnergyCombinator,
+                   "ManualHierarchicalEnergyCombinator": E.ManualHierarchicalEnergyCombinator}
+
+        class _U(pickle.Unpickler):
+            def find_class(self, module, name):
+                if name in allowed:
+                    return allowed[name]
+                if module.startswith("numpy"):
+                    return super().find_class(module, name)
+                raise pickle.UnpicklingError(f"refusing to load {module}.{name}")
+
+        with open(pk, "rb") as f:
+            return _U(f).load()
+    raise FileNotFoundError(js)
+
+
+class MPPModel:
+    def __init__(self, config: Dict, phase: str = "val", overwrite: bool = False, load: bool = False,
+                 dataset: str = None, device: int = 0, nets=None, spec_waves: int = 8):
+        assert phase in ["val", "train"]
+        self.config = config
+        self.save_path = os.path.join(get_model_base_path(), "mpp", config["model_name"])
+        os.makedirs(self.save_path, exist_ok=True)
+        if dataset is not None:
+            self.config["dataset"]["dataset"] = dataset
+        self.rng = np.random.default_rng(0)                       # reference mpp_model.py:52
+        self.dataset = self.config["dataset"]["dataset"]
+        self.position_model = self.config["dataset"]["position_model"]
+        self.shape_model = self.config["dataset"]["shape_model"]
+        self.device, self.nets, self.spec_waves = device, nets, spec_waves
+        logging.basicConfig(format="%(levelname)-8s [%(filename)s:%(lineno)d] %(message)s", level=logging.INFO)
+
+        kind = self.config.get("energy_setup") or "legacy"
+        params = self.config.get("energy_setup_params") or {}
+        if kind == "legacy":
+            self.energy_setup = E.LegacyEnergySetup(calibration_params=self.config.get("calibration", {}).get("params", {}))
+        elif kind == "no-calibration":
+            self.energy_setup = E.NoCalibrationEnergySetup(**params)
+        elif kind == "contrast":
+            raise NotImplementedError("energy_setup 'contrast' (reference energy_setup_contrast.py) is not built")
+        else:
+            print("energy_setup must be one of : 'legacy', 'no-calibration', 'contrast'")
+            raise ValueError(kind)
+        logging.info(f"using {kind} energies {self.energy_setup.energy_names}")
+        self.energy_model = None
+        if load:
+            self.energy_setup.load_calibration(self.save_path)
+            try:
+                self.energy_model = load_energy_combinator(self.save_path)
+            except FileNotFoundError:
+                if self._find_train_mode() == "manual":
+                    self.train()
+                else:
+                    raise
+        else:
+            raise NotImplementedError("calibration / weight learning are outside this build: start from a stored "
+                                      "model (calibration.json + energy_combination_model.json)")
+
+    def _find_train_mode(self):
+        modes = [t for t in TRAIN_MODES if t in self.config]
+        if len(modes) > 1:
+            logging.error(f"found {modes} in model config : can only have one train mode")
+            raise ValueError
+        return modes[0] if modes else None
+
+    def train(self):
+        mode = self._find_train_mode()
+        if mode != "manual":
+            raise NotImplementedError(f"train mode {mode!r}: only 'manual' is built (reference mpp_model.py:155-183)")
+        m = self.config["manual"]
+        if isinstance(self.energy_setup, E.LegacyEnergySetup):
+            self.energy_model = E.hierarchical_from_manual(m)
+            d = {"type": "HierarchicalEnergyCombinator", "weights_data": self.energy_model.weights_data.tolist(),
+                 "weights_prior": self.energy_model.weights_prior.tolist(),
+                 "data_prior_weights": self.energy_model.data_prior_weights.tolist(),
+                 "detection_threshold": self.energy_model.detection_threshold, "bias": 0.0}
+        else:
+            self.energy_model = E.ManualHierarchicalEnergyCombinator(m.get("weights"), m.get("indicator_energy"),
+                                                                     m.get("threshold"))
+            d = {"type": "ManualHierarchicalEnergyCombinator", "weights_dict": m.get("weights"),
+                 "indicator_energy": m.get("indicator_energy"), "detection_threshold": m.get("threshold")}
+        with open(os.path.join(self.save_path, "energy_combination_model.json"), "w") as f:
+            json.dump(d, f, indent=1)
+
+    # ------------------------------------------------------------------------------------------------
+    def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1):
+        """Tile, sample, merge and score one image.  Returns (EPointsSet of detections, scores)."""
+        shape = image_data.shape[:2]
+        patch = min(PATCH_SIZE, shape[0], shape[1])
+        anchors = tile_anchors(shape, patch)
+        tiles = [crop_image_w_maps(image_data, a, patch) for a in anchors]
+        mine = mdist.shard_tiles(len(tiles), rank, world_size)
+        p = self.config["inference"]["rjmcmc_params"]
+        alpha, T_target, total, snaps = resolve_schedule(1, p["init_temperature"], p["alpha_t"], p["burn_in"],
+                                                          p["samples_interval"], p["target_temperature"],
+                                                          p.get("iter_multiplier"))
+        results: List[List[Rectangle]] = [[] for _ in tiles]
+        start = time.perf_counter()
+        if mine:
+            sampler = TileBatchSampler([tiles[i] for i in mine], self.energy_setup, self.energy_model,
+                                       device=self.device, spec_waves=self.spec_waves)
+            sampler.init("naive")
+            seed = int(self.rng.integers(0, 2 ** 63 - 1))
+            out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0])
+            for i, res in zip(mine, out):
+                results[i] = res[-1]
+            logging.info(f"ran {len(mine)} rjmcmc chains of {total} steps in one launch in "
+                         f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
+        if world_size > 1:                      # one all-gather of the fixed-capacity detection buffer
+            pts = [(np.array([[r.x, r.y] for r in results[i]], dtype=float).reshape(-1, 2),
+                    np.array([[r.size, r.ratio, r.angle] for r in results[i]], dtype=float).reshape(-1, 3)) for i in mine]
+            buf = mdist.pack_detections(mine, pts, [None] * len(mine), capacity=1024 * max(1, len(mine)))
+            rec = mdist.all_gather_detections(buf, device=f"cuda:{self.device}")
+            results = [[] for _ in tiles]
+            for r in rec:
+                results[int(r[0])].append(Rectangle(int(r[1]), int(r[2]), size=float(r[3]), ratio=float(r[4]),
+                                                    angle=float(r[5])))
+        logging.info(f"merging {len(tiles)} patches ...")
+        merged = merge_patches(patches=tiles, results=results, original_image=image_data, method="distance",
+                               energy_model=self.energy_model, distance=3, energy_setup=self.energy_setup)
+        scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
+        return merged, scores
+
+    def infer(self, subset: str, min_confidence: float = 0.1, display_min_confidence: float = 0.5,
+              overwrite: bool = True):
+        """Reference ``mpp_model.py:202-370`` (figures are not drawn)."""
+        rank, world = mdist.init_process_group()
+        dataset = self.config["dataset"]["dataset"]
+        results_dir = get_inference_path(os.path.split(self.save_path)[1], dataset, subset)
+        os.makedirs(results_dir, exist_ok=True)
+        tr = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"])
+        tr_sv = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"], postfix="-SV")
+        id_re = re.compile(r"([0-9]+).*.png")
+        for pf in fetch_data_paths(dataset, subset)["images"]:
+            patch_id = int(id_re.match(os.path.split(pf)[1]).group(1))
+            out_file = os.path.join(results_dir, f"{patch_id:04}_results.pkl")
+            if os.path.exists(out_file) and not overwrite:
+                print(f"{patch_id:04}_results.pkl exists, skipping")
+                continue
+            image_data = load_image_w_maps(patch_id, dataset=dataset, subset=subset, position_model=self.position_model,
+                                           shape_model=self.shape_model, nets=self.nets)
+            merged, scores = self.infer_image(image_data, rank, world)
+            if rank != 0:
+                continue
+            pts = list(merged)
+            pred_params = [sra_to_wla(p.size, p.ratio, p.angle) for p in pts]
+            pred_centers = np.array([[p.x, p.y] for p in pts]).reshape(-1, 2)
+            labels = image_data.labels
+            gt_poly = np.array([rect_to_poly(c, short=q[0], long=q[1], angle=q[2])
+                                for c, q in zip(labels["centers"], labels["parameters"])]).reshape(-1, 4, 2)
+            det_poly = np.array([rect_to_poly(c, q[0], q[1], q[2]) for c, q in zip(pred_centers, pred_params)]).reshape(-1, 4, 2)
+            difficult = labels.get("difficult", np.zeros(len(gt_poly), int))
+            cats = labels.get("categories", ["vehicle"] * len(gt_poly))
+            tr.add_gt(image_id=patch_id, polygons=gt_poly, difficulty=difficult, categories=["vehicle"] * len(gt_poly))
+            tr_sv.add_gt(image_id=patch_id, polygons=gt_poly,
+                         difficulty=[bool(d) or c == "large-vehicle" for d, c in zip(difficult, cats)],
+                         categories=["vehicle"] * len(gt_poly))
+            max_score = self.config["inference"].get("max_score") or 4.0
+            score01 = np.asarray(scores) / max_score
+            if len(score01) > 0 and np.max(score01) > 1.0:
+                logging.warning(f"pred score higher than max, effective score is {np.max(scores)} while param says {max_score}")
+            for t in (tr, tr_sv):
+                t.add_detections(image_id=patch_id, scores=score01, polygons=det_poly, flip_coor=True,
+                                 class_names=["vehicle"] * len(score01))
+            with open(out_file, "wb") as f:
+                pickle.dump({"detection": det_poly, "detection_points": [p.as_row() for p in pts],
+                             "detection_type": "poly", "detection_center": pred_centers,
+                             "detection_score": list(map(float, scores)), "detection_params": pred_params}, f)
+        if rank == 0:
+            tr.save()
+            tr_sv.save()
+            print("saved dota translation")
+
+    def eval(self):
+        raise NotImplementedError("the DOTA mAP evaluator (un-vendored DOTA_devkit in the reference, "
+                                  "metrics/dota_eval.py:37-38) is listed as a next step in DESIGN.md")
+
+    def data_preview(self):
+        raise NotImplementedError("figures are outside this build")

@@ -1,0 +1,205 @@
+"""PosNet / ShapeNet: the two U-Nets that produce the score maps the sampler runs on.
+
+Same architecture and the same ``state_dict`` keys as the reference (``model_parts/unet/unet.py:24-60``,
+``unet_parts.py:12-67``, ``models/position_net/pos_net.py:9-30``, ``models/shape_net/shape_net.py:12-46``) so a
+user's ``model.pt`` loads unchanged:  3x3 reflect-padded conv + BatchNorm + ReLU twice per level,
+2x2 max-pool down, 2x2 stride-2 transposed conv up, skip concat ``[skip, up]``, 1x1 heads.
+
+MI355X use: convolutions go through PyTorch-ROCm (MIOpen -> MFMA), in channels-last layout; the
+post-processing of both nets (sigmoid / divergence / 1x1 classifier / sigmoid, and softmax +
+CHW->HWC) is fused into two hand-written HIP kernels (``csrc/mpp_maps.hip``) whose outputs stay on
+the device in exactly the layout the sampler reads -- the reference's pickle round trip
+(``pos_net_model.py:407-424`` -> ``data_loaders.py:30-71``) disappears.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+HIDDEN_DIMS = (32, 64, 128, 256)
+DIV_CLF_W, DIV_CLF_B = -10.812359809875488, -2.128434181213379   # models_storage/posnet/posvec_dota/model_div_clf.pt
+
+
+class DoubleConv(nn.Module):
+    def __init__(self, c_in: int, c_out: int):
+        super().__init__()
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(c_in, c_out, kernel_size=(3, 3), padding=1, padding_mode="reflect"),
+            nn.BatchNorm2d(c_out), nn.ReLU(inplace=True),
+            nn.Conv2d(c_out, c_out, kernel_size=(3, 3), padding=1, padding_mode="reflect"),
+            nn.BatchNorm2d(c_out), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.double_conv(x)
+
+
+class Down(nn.Module):
+    def __init__(self, c_in: int, c_out: int):
+        super().__init__()
+        self.maxpool_conv = nn.Sequential(nn.MaxPool2d(2), DoubleConv(c_in, c_out))
+
+    def forward(self, x):
+        return self.maxpool_conv(x)
+
+
+class Up(nn.Module):
+    def __init__(self, c_in: int, c_out: int):
+        super().__init__()
+        self.up = nn.ConvTranspose2d(c_in, c_in // 2, kernel_size=(2, 2), stride=(2, 2))
+        self.conv = DoubleConv(c_in, c_out)
+
+    def forward(self, x, skip):
+        return self.conv(torch.cat([skip, self.up(x)], dim=1))
+
+
+class Unet(nn.Module):
+    def __init__(self, hidden_dims: Sequence[int] = HIDDEN_DIMS, in_channels: int = 3, device=None):
+        super().__init__()
+        self.descending_path = nn.ModuleList()
+        c = in_channels
+        for i, h in enumerate(hidden_dims):
+            self.descending_path.append(DoubleConv(c, h) if i == 0 else Down(c, h))
+            c = h
+        self.ascending_path = nn.ModuleList()
+        for h in list(hidden_dims)[::-1][1:]:
+            self.ascending_path.append(Up(c, h))
+            c = h
+        self.out_channels = c
+        self.depth = len(hidden_dims) - 1
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x.float()
+        skips = []
+        for down in self.descending_path:
+            x = down(x)
+            skips.append(x)
+        for up, skip in zip(self.ascending_path, skips[::-1][1:]):
+            x = up(x, skip)
+        return x
+
+
+class PosNet(nn.Module):
+    """3 output channels: vector field (2) + mask logit (reference ``pos_net.py:9-30``)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, device=None, hidden_dims: Sequence[int] = HIDDEN_DIMS):
+        super().__init__()
+        self.backbone = Unet(hidden_dims, in_channels)
+        self.final_layer = nn.Conv2d(self.backbone.out_channels, out_channels, kernel_size=(1, 1))
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.final_layer(self.backbone(x))
+
+
+class ShapeNet(nn.Module):
+    """Three 1x1 heads of 32 logits each: size, ratio, angle (reference ``shape_net.py:12-46``)."""
+
+    def __init__(self, in_channels: int = 3, out_features: int = 3, out_feat_size=32, device=None,
+                 hidden_dims: Sequence[int] = HIDDEN_DIMS):
+        super().__init__()
+        self.backbone = Unet(hidden_dims, in_channels)
+        sizes = [out_feat_size] * out_features if isinstance(out_feat_size, int) else list(out_feat_size)
+        self.final_layers = nn.ModuleList(
+            [nn.Sequential(nn.Conv2d(self.backbone.out_channels, s, kernel_size=(1, 1))) for s in sizes])
+
+    def forward(self, x: Tensor) -> List[Tensor]:
+        h = self.backbone(x)
+        return [fl(h) for fl in self.final_layers]
+
+    def forward_with_softmax(self, x: Tensor, temperature: float = 1.0) -> List[Tensor]:
+        return [torch.softmax(t / temperature, dim=1) for t in self.forward(x)]
+
+
+def pad_before_infer(image: Tensor, depth: int) -> Tuple[Tensor, List[int]]:
+    """Zero-pad bottom/right to a multiple of 2**depth (reference ``unet.py:9-21``); image is [C,H,W]."""
+    div = 2 ** depth
+    pad = [(div - s % div) % div for s in image.shape[1:]]
+    if pad[0] or pad[1]:
+        image = F.pad(image, pad=(0, pad[1], 0, pad[0]))
+    return image, pad
+
+
+# ---- plain-torch post-processing: the float32 reference the HIP epilogues are tested against ----------
+def torch_divergence_ij(vec: Tensor) -> Tensor:
+    """d vec[0]/d row + d vec[1]/d col with ``torch.gradient`` (reference ``torch_div.py:8-27``, 'ij')."""
+    return torch.gradient(vec[0], dim=0)[0] + torch.gradient(vec[1], dim=1)[0]
+
+
+def detection_map_torch(pos_out: Tensor, H: int, W: int, w: float = DIV_CLF_W, b: float = DIV_CLF_B) -> Tensor:
+    """pos_out [3,Hp,Wp] -> det [H,W] (reference ``pos_net_model.py:186-200`` crop, then ``:338-346``)."""
+    out = pos_out[:, :H, :W].float()
+    mask = torch.sigmoid(out[2])
+    return torch.sigmoid(w * (torch_divergence_ij(out[:2]) * mask) + b)
+
+
+def marks_torch(logits: Sequence[Tensor], H: int, W: int) -> List[Tensor]:
+    """three [32,Hp,Wp] logits -> three [H,W,32] softmax maps (``shape_net_model.py:139-141`` + ``data_loaders.py:54``)."""
+    return [torch.softmax(t[:, :H, :W].float(), dim=0).permute(1, 2, 0).contiguous() for t in logits]
+
+
+def load_div_clf(model_dir: str) -> Tuple[float, float]:
+    """The two scalars of the 1x1 'div_clf' conv: ``model_div_clf.pt`` (reference) or its JSON twin."""
+    pt, js = os.path.join(model_dir, "model_div_clf.pt"), os.path.join(model_dir, "model_div_clf.json")
+    if os.path.exists(pt):
+        sd = torch.load(pt, map_location="cpu", weights_only=True)
+        return float(sd["1.weight"].flatten()[0]), float(sd["1.bias"].flatten()[0])
+    if os.path.exists(js):
+        with open(js) as f:
+            d = json.load(f)
+        return float(d["weight"]), float(d["bias"])
+    return DIV_CLF_W, DIV_CLF_B
+
+
+def load_torch_model(module: nn.Module, model_dir: str) -> bool:
+    """``TorchModel._load`` (reference ``base/base_model.py:35-49``): model.pt, else the last checkpoint_*.pt."""
+    import glob
+    path = os.path.join(model_dir, "model.pt")
+    if not os.path.exists(path):
+        ck = sorted(glob.glob(os.path.join(model_dir, "checkpoint_*.pt")))
+        if not ck:
+            return False
+        path = ck[-1]
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    module.load_state_dict(sd.get("model_state_dict", sd) if isinstance(sd, dict) else sd)
+    return True
+
+
+class ScoreMapNets:
+    """PosNet + ShapeNet inference on one GPU with the fused HIP epilogues."""
+
+    def __init__(self, posnet: PosNet, shapenet: ShapeNet, device: int = 0, div_clf: Tuple[float, float] = None,
+                 dtype: torch.dtype = torch.float32, ctx=None):
+        from .hip_api import MppContext
+        self.device = torch.device("cuda", device)
+        self.pos = posnet.to(self.device).eval().to(memory_format=torch.channels_last)
+        self.shp = shapenet.to(self.device).eval().to(memory_format=torch.channels_last)
+        self.div_w, self.div_b = div_clf or (DIV_CLF_W, DIV_CLF_B)
+        self.dtype = dtype
+        self.ctx = ctx or MppContext(device)
+
+    @torch.no_grad()
+    def infer(self, image) -> Tuple[Tensor, List[Tensor]]:
+        """image: [H,W,3] float in [0,1] (numpy or tensor) -> det [H,W] f32, marks 3 x [H,W,32] f32, on the GPU."""
+        img = torch.as_tensor(np.asarray(image) if not torch.is_tensor(image) else image)
+        img = img[..., :3].permute(2, 0, 1).float().to(self.device)
+        H, W = img.shape[1:]
+        padded, _ = pad_before_infer(img, self.pos.backbone.depth)
+        x = padded.unsqueeze(0).contiguous(memory_format=torch.channels_last)
+        with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
+            pos_out = self.pos(x)
+            logits = self.shp(x)
+        pos_out = pos_out[0].float().contiguous()
+        logits = [t[0].float().contiguous() for t in logits]
+        det = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        marks = [torch.empty((H, W, 32), dtype=torch.float32, device=self.device) for _ in range(3)]
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        self.ctx.posnet_epilogue(pos_out, H, W, self.div_w, self.div_b, det)
+        for k in range(3):
+            self.ctx.shapenet_epilogue(logits[k], H, W, marks[k])
+        self._keep = (pos_out, logits)        # alive until the kernels on this stream have consumed them
+        return det, marks

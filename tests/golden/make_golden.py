@@ -373,8 +373,26 @@ def make_unet_golden():
     print("wrote unet_golden.npz", os.path.getsize(os.path.join(HERE, "unet_golden.npz")) // 1024, "KiB")
 
 
+def make_perturbation_golden():
+    """sample_perturbations (plain numpy draws): outputs for fixed seeds and the four presets."""
+    from models.mpp import perturbation_sampler as ps
+    tile = synth.make_tile(96, 15, tile_id=6)
+    image_data = image_data_from(tile)
+    out = {"gt_xy": tile.gt_xy, "gt_marks": tile.gt_marks}
+    for name in ("PERTURBATION_LIGHT", "PERTURBATION_MEDIUM", "PERTURBATION_MEDIUM_OVERLAP", "PERTURBATION_STRONG"):
+        rng = np.random.default_rng(123)
+        res = ps.sample_perturbations(image_data=image_data, rng=rng, n_samples=3, **getattr(ps, name))
+        out[name + "_len"] = np.array([len(r) for r in res])
+        out[name + "_flat"] = np.array([rect_row(p) for r in res for p in r], dtype=float).reshape(-1, 5)
+        out[name + "_next"] = rng.random()           # the generator must end in the same state
+    np.savez_compressed(os.path.join(HERE, "perturbations_golden.npz"), **out)
+    print("wrote perturbations_golden.npz")
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["tapes", "delta", "unet"]
+    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert"]
+    if "pert" in what:
+        make_perturbation_golden()
     if "tapes" in what:
         make_tapes()
     if "delta" in what:

@@ -1,0 +1,107 @@
+"""Host-side logic that needs no GPU: schedule arithmetic, perturbation sampling (against vectors
+recorded from the reference), aggregation, kernel mixture, energy-setup tables, tile sharding."""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, hrc_model, log_model
+from mpp_cnn_rs_object_detection_amd import distributed as mdist
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import kernels, mappings, synth
+from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps, Perturbation
+from mpp_cnn_rs_object_detection_amd.shapes import Rectangle, rect_to_poly, sra_to_wla, wla_to_sra
+
+
+def test_schedule_matches_reference_arithmetic():
+    from mpp_cnn_rs_object_detection_amd.sampler import resolve_schedule
+    # mpp_hrcM: burn_in 30000, interval 128, one sample -> max_iter 30256, 30257 steps; the returned state is
+    # the one after step 30208 = 236*128, NOT the last one
+    alpha, Tt, total, snaps = resolve_schedule(1, 1.0, 0.999, 30000, 128, 0.0)
+    assert (alpha, Tt, total) == (0.999, 0.0, 30257)
+    assert snaps == [30080, 30208]
+    # mpp_log: interval 1 -> samples at 30000, 30001, 30002; 30003 steps
+    alpha, Tt, total, snaps = resolve_schedule(1, 1.0, 0.999, 30000, 1, 0.0)
+    assert total == 30003 and snaps[-1] == 30002
+    alpha, Tt, total, snaps = resolve_schedule(1, 1.0, "auto", 1000, 10, 1e-3)
+    assert Tt == 0 and alpha == pytest.approx((1e-3) ** (1 / 1000))
+    alpha, Tt, total, snaps = resolve_schedule(1, 1.0, 0.99, 100, 10, 0.0, iter_multiplier=2)
+    assert alpha == pytest.approx(0.99 ** 0.5) and total == 200 + 2 * 20 + 1
+
+
+def test_sample_perturbations_matches_reference_vectors():
+    from mpp_cnn_rs_object_detection_amd import perturbation_sampler as ps
+    z = np.load(f"{GOLDEN}/perturbations_golden.npz")
+    gt = [Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2]))
+          for (x, y), m in zip(z["gt_xy"], z["gt_marks"])]
+    data = ImageWMaps(name="0", shape=(96, 96), image=None, detection_map=None, param_dist_maps=None,
+                      mappings=mappings.default_mappings(), param_names=Rectangle.PARAMETERS, gt_config=gt)
+    for name in ("PERTURBATION_LIGHT", "PERTURBATION_MEDIUM", "PERTURBATION_MEDIUM_OVERLAP", "PERTURBATION_STRONG"):
+        rng = np.random.default_rng(123)
+        res = ps.sample_perturbations(image_data=data, rng=rng, n_samples=3, **getattr(ps, name))
+        assert [len(r) for r in res] == list(z[name + "_len"])
+        flat = np.array([p.as_row() for r in res for p in r], dtype=float).reshape(-1, 5)
+        np.testing.assert_array_equal(flat, z[name + "_flat"])
+        assert rng.random() == float(z[name + "_next"])
+
+
+def test_aggregate_perturbations():
+    from mpp_cnn_rs_object_detection_amd.perturbation_sampler import aggregate_perturbations
+    a, b, c = (Rectangle(1, 1, 1, 1, 0), Rectangle(2, 2, 1, 1, 0), Rectangle(3, 3, 1, 1, 0))
+    agg = aggregate_perturbations([Perturbation(None, addition=a), Perturbation(None, removal=b),
+                                   Perturbation(None, removal=a), Perturbation(None, removal=c, addition=b)])
+    assert agg.addition == [] and agg.removal == [c]
+
+
+def test_kernel_mixture_is_the_reference_one():
+    k = kernels.make_kernels(mappings.default_mappings(), 7)
+    np.testing.assert_allclose(k.p_kernel, [1 / 18, 1 / 18, 1 / 9, 1 / 9, 1 / 9, 2 / 9, 1 / 9, 2 / 9], rtol=1e-15)
+    assert k.intensity == 7 and k.max_delta == 8 and k.sigma_trans == 2.0 and k.sigma_transform == 0.1
+    with pytest.raises(NotImplementedError):
+        kernels.make_kernels(mappings.default_mappings(), 1, use_split_merge=True)
+
+
+def test_energy_tables():
+    setup, comb = hrc_model()
+    unit, pair = setup.make_energies()
+    d = E.build_model_desc(unit, pair, comb)
+    assert d.names == ["PositionEnergy", "ShapeEnergy", "AreaPriorEnergy", "RectangleOverlapEnergy",
+                       "ShapeAlignmentEnergy"]
+    assert d.gate_term == 0 and d.combinator == E.C_LINEAR
+    coef = [u[2] for u in d.unit] + [p[3] for p in d.pair]
+    np.testing.assert_allclose(coef, [0.5 * 0.8, 0.5 * 0.2, 0.5 * 0.2 / 0.85, 0.5 * 0.6 / 0.85, 0.5 * 0.05 / 0.85])
+    assert setup.detection_threshold == pytest.approx(0.6464646464646465)
+    setup, comb = log_model()
+    unit, pair = setup.make_energies()
+    d = E.build_model_desc(unit, pair, comb)
+    assert d.combinator == E.C_LOGISTIC and d.gate_term == -1
+    assert d.lin0 == pytest.approx(8 * 0.7927545309066772)       # the bias enters once per term
+    assert setup.detection_threshold == 0.5
+    # the host-side combinators compute what the flattened tables describe
+    vec = {n: [0.3 * (i + 1), -0.2 * i] for i, n in enumerate(setup.energy_names)}
+    lin = d.lin0 + sum(c * np.array(vec[n]) for n, c in zip(d.names, [u[2] for u in d.unit] + [p[3] for p in d.pair]))
+    assert comb.compute(vec) == pytest.approx(float(np.sum(2 / (1 + np.exp(-lin)) - 1)))
+
+
+def test_shapes_and_mappings():
+    r = Rectangle(10, 20, size=6.0, ratio=0.5, angle=0.3)
+    assert r.length == pytest.approx(8.0) and r.width == pytest.approx(4.0)
+    poly = r.poly_coord
+    x, y = poly[:, 0], poly[:, 1]
+    area = 0.5 * abs(np.dot(x, np.roll(y, -1)) - np.dot(y, np.roll(x, -1)))
+    assert area == pytest.approx(32.0)
+    assert wla_to_sra(*sra_to_wla(6.0, 0.5, 0.3)) == pytest.approx((6.0, 0.5, 0.3))
+    assert rect_to_poly((0, 0), 2, 4, 0.0).tolist() == [[1, 2], [1, -2], [-1, -2], [-1, 2]]
+    m = mappings.default_mappings()[2]
+    assert m.value_to_class(m.class_to_value(17)) == 17
+    assert m.clip(np.pi + 0.1) == pytest.approx(0.1)
+    assert mappings.default_mappings()[0].clip(40.0) == 32.0
+
+
+def test_tile_sharding_and_detection_packing():
+    assert mdist.shard_tiles(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum([mdist.shard_tiles(16, r, 8) for r in range(8)], [])) == list(range(16))
+    pts = [(np.array([[1, 2], [3, 4]]), np.array([[5., .5, 1.], [6., .6, 2.]])), (np.zeros((0, 2)), np.zeros((0, 3)))]
+    buf = mdist.pack_detections([3, 7], pts, [np.array([.9, .8]), np.zeros(0)], capacity=8)
+    rec = mdist.unpack_detections(buf[None])
+    assert rec.shape == (2, 7) and rec[0].tolist() == [3, 1, 2, 5, .5, 1, .9]
+    with pytest.raises(ValueError):
+        mdist.pack_detections([0], [pts[0]], [None], capacity=1)

@@ -1,0 +1,101 @@
+"""U-Nets: state_dict compatibility and outputs against vectors recorded from the reference modules
+(tests/golden/unet_golden.npz); the HIP epilogues against plain-torch float32 post-processing."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN
+from mpp_cnn_rs_object_detection_amd import unet
+
+
+def recipe_state_dict(module, seed):
+    """Same recipe as tests/golden/make_golden.py: weights keyed by position in the sorted key list."""
+    sd = module.state_dict()
+    new = {}
+    for i, k in enumerate(sorted(sd.keys())):
+        v = sd[k]
+        g = torch.Generator().manual_seed(seed * 1000 + i)
+        if k.endswith("num_batches_tracked"):
+            new[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            new[k] = 0.5 + torch.rand(v.shape, generator=g)
+        elif k.endswith("running_mean"):
+            new[k] = 0.1 * torch.randn(v.shape, generator=g)
+        elif v.dim() >= 2:
+            new[k] = torch.randn(v.shape, generator=g) * (2.0 / v[0].numel()) ** 0.5
+        elif k.endswith("weight"):
+            new[k] = 1.0 + 0.1 * torch.randn(v.shape, generator=g)
+        else:
+            new[k] = 0.05 * torch.randn(v.shape, generator=g)
+    return new
+
+
+@pytest.fixture(scope="module")
+def nets():
+    pos, shp = unet.PosNet(), unet.ShapeNet()
+    pos.load_state_dict(recipe_state_dict(pos, 1))
+    shp.load_state_dict(recipe_state_dict(shp, 2))
+    return pos.eval(), shp.eval()
+
+
+def test_state_dict_keys_and_sizes_match_reference(nets):
+    z = np.load(f"{GOLDEN}/unet_golden.npz")
+    pos, shp = nets
+    assert sorted(pos.state_dict().keys()) == [str(k) for k in z["keys_pos"]]
+    assert sorted(shp.state_dict().keys()) == [str(k) for k in z["keys_shp"]]
+    assert sum(p.numel() for p in pos.parameters()) == int(z["n_params_pos"]) == 1928483
+    assert sum(p.numel() for p in shp.parameters()) == int(z["n_params_shp"]) == 1931552
+
+
+def test_forward_matches_reference_outputs_cpu(nets):
+    z = np.load(f"{GOLDEN}/unet_golden.npz")
+    pos, shp = nets
+    img = torch.from_numpy(z["image"])
+    H, W = img.shape[1:]
+    with torch.no_grad():
+        padded, pad = unet.pad_before_infer(img, 3)
+        assert tuple(padded.shape[1:]) == (48, 56) and pad == [4, 4]
+        out = pos(padded.unsqueeze(0))[0]
+        logits = [t[0] for t in shp(padded.unsqueeze(0))]
+    np.testing.assert_allclose(out[:, :H, :W].numpy(), z["pos_out"], rtol=1e-4, atol=1e-5)
+    det = unet.detection_map_torch(out, H, W, float(z["div_w"]), float(z["div_b"]))
+    np.testing.assert_allclose(det.numpy(), z["det"], rtol=1e-4, atol=1e-6)
+    marks = unet.marks_torch(logits, H, W)
+    got = np.stack([m.permute(2, 0, 1).numpy() for m in marks])
+    np.testing.assert_allclose(got[:, :, ::7, ::5], z["shape_out_sample"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got, z["shape_out"].astype(np.float32), atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_hip_epilogues_match_torch_float32(nets):
+    from mpp_cnn_rs_object_detection_amd import hip_api
+    z = np.load(f"{GOLDEN}/unet_golden.npz")
+    pos, shp = nets
+    import copy
+    runner = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0,
+                               div_clf=(float(z["div_w"]), float(z["div_b"])))
+    img = torch.from_numpy(z["image"]).permute(1, 2, 0).contiguous()
+    det, marks = runner.infer(img)
+    torch.cuda.synchronize()
+    # against the reference's recorded outputs (whole pipeline on the GPU)
+    np.testing.assert_allclose(det.cpu().numpy(), z["det"], rtol=2e-3, atol=2e-4)
+    got = np.stack([m.permute(2, 0, 1).cpu().numpy() for m in marks])
+    np.testing.assert_allclose(got, z["shape_out"].astype(np.float32), atol=3e-3)
+    # epilogues alone, same inputs, against plain torch float32 of the same op (tolerance 1e-5:
+    # float32 expf differs in the last ulp between ocml and torch's kernels)
+    g = torch.Generator().manual_seed(0)
+    for (H, W, Hp, Wp) in ((44, 52, 48, 56), (64, 64, 64, 64), (33, 129, 40, 136), (1, 70, 8, 72)):
+        pos_out = torch.randn((3, Hp, Wp), generator=g).cuda()
+        logits = (3.0 * torch.randn((32, Hp, Wp), generator=g)).cuda()
+        d = torch.empty((H, W), device="cuda")
+        m = torch.empty((H, W, 32), device="cuda")
+        runner.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        runner.ctx.posnet_epilogue(pos_out, H, W, -10.8, -2.1, d)
+        runner.ctx.shapenet_epilogue(logits, H, W, m)
+        torch.cuda.synchronize()
+        if H > 1:
+            ref_d = unet.detection_map_torch(pos_out.cpu(), H, W, -10.8, -2.1)
+            np.testing.assert_allclose(d.cpu().numpy(), ref_d.numpy(), rtol=1e-5, atol=1e-6)
+        ref_m = unet.marks_torch([logits.cpu()], H, W)[0]
+        np.testing.assert_allclose(m.cpu().numpy(), ref_m.numpy(), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(m.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
