@@ -75,6 +75,7 @@ def all_gather_detections(local: np.ndarray, device=None) -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(local))
     if device is not None:
         t = t.to(device)
-    out = torch.empty((dist.get_world_size(),) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    world = dist.get_world_size()
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenated form
     dist.all_gather_into_tensor(out, t)
-    return unpack_detections(out.cpu().numpy())
+    return unpack_detections(out.reshape((world,) + tuple(t.shape)).cpu().numpy())
