@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--objects", type=int, default=200)
     ap.add_argument("--spec", type=int, default=int(os.environ.get("MPP_SPEC_WAVES", "8")))
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("MPP_SPEC_LANES", "0")),
+                    help="lane mode: 4 waves x LANES lanes, one speculative step per lane (0 = one wave per step)")
     ap.add_argument("--tiles-per-gpu", type=int, default=1)
     ap.add_argument("--cpu-baseline-chains", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -74,7 +76,7 @@ def main():
     maps = mappings.default_mappings()
     T = args.tiles_per_gpu
     tiles = [synth.make_tile(args.tile, args.objects, tile_id=rank * T + i) for i in range(T)]
-    ctx = hip_api.MppContext(local, point_capacity=1024, spec_waves=args.spec)
+    ctx = hip_api.MppContext(local, point_capacity=1024, spec_waves=args.spec, spec_lanes=args.lanes)
     ctx.set_maps(np.stack([t.det for t in tiles]), [np.stack([t.marks[k] for t in tiles]) for k in range(3)])
     ctx.set_model(model, maps)
     ctx.naive_init(setup.detection_threshold, 6.0)
@@ -140,7 +142,7 @@ def main():
         "config": {
             "workload": f"{T} x single {args.tile}x{args.tile} synthetic tile per GPU, {args.objects} objects, "
                         f"mpp_hrcM energies, {args.iters} RJMCMC steps per chain (T0=1, alpha=0.999), naive init",
-            "iters_per_step": args.iters, "tiles_per_gpu": T, "spec_waves": args.spec,
+            "iters_per_step": args.iters, "tiles_per_gpu": T, "spec_waves": args.spec, "spec_lanes": args.lanes,
             "parallelism": f"tile-parallel x{world}, one all-gather of detections" if world > 1 else "1 tile, 1 workgroup",
             "accept_rate": acc, "mean_points": mean_n, "final_points": int(len(final_xy)),
             "gt_matched_within_2px": matched, "gt_objects": int(len(tiles[0].gt_xy)),

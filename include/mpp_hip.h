@@ -114,8 +114,9 @@ const char *mpp_last_error(mpp_ctx *ctx);
 /* use an existing hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
 int mpp_set_stream(mpp_ctx *ctx, void *hip_stream);
 int mpp_synchronize(mpp_ctx *ctx);
-/* "spec_waves": proposals evaluated speculatively per round (1 = strictly one at a time; results
- * are identical for every value), "point_capacity": slots per tile, "cell_capacity" (points per
+/* "spec_waves": proposals evaluated speculatively per round, one wave each (1 = strictly one at a
+ * time); "spec_lanes" (0 = off): lane mode, 4 waves of which `v` lanes each evaluate one step on
+ * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile, "cell_capacity" (points per
  * 32-px cell), "force_accept": apply every proposal without the Metropolis test (the kernel random
  * walks of models/mpp/perturbation_sampler.py:152-169) */
 int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);

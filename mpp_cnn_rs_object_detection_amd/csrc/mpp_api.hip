@@ -9,8 +9,8 @@
 
 #include "mpp_device.hpp"
 
-extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec);
-extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int grid, size_t lds, const DevParams *P,
+extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n);
+extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int grid, size_t lds, const DevParams *P,
                                        const TileRef *tiles, int tile0, long long n_steps, unsigned long long seed,
                                        unsigned int chain0, const mpp_proposal *tape, int trace_tile,
                                        mpp_step_out *out, mpp_proposal *props);
@@ -45,7 +45,7 @@ struct mpp_ctx {
   float *det = nullptr, *m[3] = {nullptr, nullptr, nullptr};
   double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
   bool box_dirty = true;
-  int cap = 1024, cell_cap = 32, spec = 1;
+  int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
   int64_t *step = nullptr;
@@ -159,6 +159,10 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   if (!strcmp(name, "spec_waves")) {
     if (v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_waves must be 1, 2, 4, 8 or 16");
     c->spec = (int)v;
+  } else if (!strcmp(name, "spec_lanes")) {
+    // lane mode: 4 waves, `v` lanes of each evaluate one speculative step each (4*v steps per round); 0 = off
+    if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_lanes must be 0, 1, 2, 4, 8 or 16");
+    c->lanes = (int)v;
   } else if (!strcmp(name, "point_capacity")) {
     if (c->have_maps) return fail(c, -1, "point_capacity must be set before mpp_set_maps");
     if (v < 1 || v > 65535) return fail(c, -1, "point_capacity out of range");
@@ -174,12 +178,15 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
 extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!c || !name) return -1;
   if (!strcmp(name, "spec_waves")) return c->spec;
+  if (!strcmp(name, "spec_lanes")) return c->lanes;
   if (!strcmp(name, "point_capacity")) return c->cap;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
   if (!strcmp(name, "lds_bytes")) {
     int ncell = c->hp.nx * c->hp.ny;
-    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, c->spec);
+    int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
+    int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
+    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb);
   }
   return -1;
 }
@@ -532,12 +539,14 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   if (rc) return rc;
   if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   const int ncell = c->hp.nx * c->hp.ny;
-  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, c->spec);
+  const int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
+  const int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
+  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, spec, rb);
   if (lds > MPP_LDS_LIMIT)
     return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
                 lds, MPP_LDS_LIMIT);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
+  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
                              d_tape, trace_tile, d_out, d_props));
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev1));

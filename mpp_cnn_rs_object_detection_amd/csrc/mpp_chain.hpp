@@ -1,0 +1,856 @@
+// mpp_sampler.hip -- the RJMCMC chain of one tile, resident in one workgroup's LDS.
+//
+// Restates (not translates) the reference's inner loop, models/mpp/rjmcmc_sampler/rjmcmc.py:83-164,
+// with its callees energy_graph.py:139-225 (dE), base_kernels.py / transform_kernels.py /
+// shape_samplers.py (proposals and their densities).
+//
+// Design (MI355X-first):
+//  * one workgroup = one tile's chain; the whole interacting point set (marks, cached corner
+//    trig, circumradius, per-point unit energy, per-point pair reductions) and the 32-px spatial
+//    hash live in LDS for the entire launch; HBM is touched only for score-map reads of proposals;
+//  * one 64-lane wave evaluates one proposal: lanes take the candidate neighbours found in the
+//    3x3 cells around the removed and the added point and compute the pair terms (rectangle
+//    clipping, alignment) against them; only the few lanes whose neighbour actually changes feed
+//    the dE sum (ballot + readlane, no 64-wide butterflies);
+//  * instead of rebuilding edges twice per step like the reference, each point caches the
+//    max/min reduction of its pair energies; a removal that takes away a point's extremum
+//    triggers a cooperative re-scan of that point's neighbourhood;
+//  * a single dependent chain of float64 transcendentals is what a step costs, so their number is
+//    kept minimal (one exp for the accept test, trig reused when the angle does not change, ...);
+//  * SPEC waves evaluate the next SPEC steps of the SAME chain speculatively against the current
+//    state, each including its own accept decision and the list of neighbour updates it would
+//    cause; wave 0 then commits them in order (a few LDS writes per accepted step) and discards
+//    everything after the first accepted step that could have influenced a later one.
+//    The chain is bit-for-bit the sequential one for every SPEC.
+#pragma once
+#include "mpp_device.hpp"
+
+#define STASH 24              // neighbour updates remembered per speculative step
+#define ERR_CELL_OVERFLOW 1
+#define ERR_POINT_OVERFLOW 2
+#define ERR_BAD_TARGET 3
+#define ERR_CAND_OVERFLOW 4
+
+#ifdef MPP_PROFILE
+// diagnostic build only: cycles per phase of wave 0, summed over the launch (never in the product build)
+__device__ unsigned long long g_prof[16];
+__device__ unsigned long long g_prof3[16];
+#define PROF_T0() unsigned long long pt_ = clock64()
+#define PROF_ADD(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof_[i] += n_ - pt_; pt_ = n_; } while (0)
+#else
+#define PROF_T0()
+#define PROF_ADD(i)
+#endif
+
+struct Rec {                  // one speculative step, fully evaluated
+  int kernel, tidx, tslot, has_rem, has_add, valid;
+  int ax, ay, rx, ry, pid, ncls;
+  int accepted, n_stash, gate_a, _pad;
+  double as, ar, aa, aux0, aux1, u_acc, qf, qb, dE;
+  double hl, hw, ca, sa, rad, lin_a, ra0, ra1;   // derived data of the proposed point
+  double fwd, bwd, log_alpha;                    // filled only when the tile is traced
+};
+
+struct Lds {
+  double *s, *r, *a, *ca, *sa, *hl, *hw, *rad, *lin, *red0, *red1;
+  double *edges;              // [3][32] copy of the mark bin edges
+  double *rowbase;            // [H+1] copy of the birth CDF's row level (lane mode, H <= 1024), else nullptr
+  double *stash_v0, *stash_v1;
+  int *xy;
+  unsigned short *order, *cell_items, *cell_cnt, *stash_slot;
+  unsigned char *gate;
+  Rec *rec;
+  int *sh;                    // [0]=n [1]=err [2]=committed ; sh[4..5] = T (double)
+};
+
+#define ROWBASE_LDS_MAX 1024
+__host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n) {
+  size_t b = 0;
+  b += (size_t)11 * cap * sizeof(double);
+  b += (size_t)rowbase_n * sizeof(double);
+  b += (size_t)3 * MPP_NCLASS * sizeof(double);
+  b += (size_t)2 * spec * STASH * sizeof(double);
+  b += (size_t)cap * sizeof(int);
+  b += (size_t)cap * sizeof(unsigned short);                  // order
+  b += (size_t)ncell * cell_cap * sizeof(unsigned short);     // cell items
+  b += (size_t)ncell * sizeof(unsigned short);                // cell counts
+  b += (size_t)spec * STASH * sizeof(unsigned short);
+  b += (size_t)cap;                                           // gate
+  b = (b + 15) & ~(size_t)15;
+  b += (size_t)spec * sizeof(Rec);
+  b += 16 * sizeof(int);
+  return b + 64;
+}
+
+__device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_cap, int spec, int rowbase_n) {
+  Lds L;
+  double *d = (double *)base;
+  L.s = d; d += cap; L.r = d; d += cap; L.a = d; d += cap; L.ca = d; d += cap; L.sa = d; d += cap;
+  L.hl = d; d += cap; L.hw = d; d += cap; L.rad = d; d += cap; L.lin = d; d += cap; L.red0 = d; d += cap;
+  L.red1 = d; d += cap;
+  L.edges = d; d += 3 * MPP_NCLASS;
+  L.rowbase = rowbase_n > 0 ? d : nullptr; d += rowbase_n;
+  L.stash_v0 = d; d += (size_t)spec * STASH; L.stash_v1 = d; d += (size_t)spec * STASH;
+  L.xy = (int *)d;
+  unsigned short *u = (unsigned short *)(L.xy + cap);
+  L.order = u; u += cap;
+  L.cell_items = u; u += (size_t)ncell * cell_cap;
+  L.cell_cnt = u; u += ncell;
+  L.stash_slot = u; u += (size_t)spec * STASH;
+  L.gate = (unsigned char *)u;
+  size_t off = (size_t)((unsigned char *)u + cap - base);
+  off = (off + 15) & ~(size_t)15;
+  L.rec = (Rec *)(base + off);
+  L.sh = (int *)(base + off + (size_t)spec * sizeof(Rec));
+  return L;
+}
+
+struct Chain {
+  const DevParams *P;
+  TileRef t;
+  Lds L;
+  int lane, wave;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS traffic of one wave is executed in order; this only stops the compiler from moving
+  // the loads of other lanes' data above the stores that produce them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ int cell_coord(const DevParams *P, int x) {
+  return P->res_shift >= 0 ? (x >> P->res_shift) : (x / P->res_int);
+}
+__device__ __forceinline__ int cell_index(const DevParams *P, int x, int y, int *ci, int *cj) {
+  int i = cell_coord(P, x), j = cell_coord(P, y);
+  *ci = i; *cj = j;
+  return j + i * P->ny;
+}
+struct Geo2 { Geo g; double rad; };
+__device__ __forceinline__ Geo2 load_geo(const Lds &L, int slot) {
+  Geo2 o;
+  int xy = L.xy[slot];
+  o.g.x = xy & 0xffff; o.g.y = (xy >> 16) & 0xffff;
+  o.g.hl = L.hl[slot]; o.g.hw = L.hw[slot]; o.g.ca = L.ca[slot]; o.g.sa = L.sa[slot];
+  o.rad = L.rad[slot];
+  return o;
+}
+__device__ __forceinline__ Rect load_rect(const Lds &L, int slot) {
+  Rect q;
+  int xy = L.xy[slot];
+  q.x = xy & 0xffff; q.y = (xy >> 16) & 0xffff;
+  q.s = L.s[slot]; q.r = L.r[slot]; q.a = L.a[slot];
+  return q;
+}
+// is slot u ordered before the rectangle (vx,vy,vs,vr,va)?  marks are read only on coordinate ties
+__device__ __forceinline__ bool slot_first(const Lds &L, int u, const Geo &gu, int vx, int vy, double vs, double vr,
+                                           double va) {
+  if (gu.x != vx) return gu.x < vx;
+  if (gu.y != vy) return gu.y < vy;
+  return rect_less(gu.x, gu.y, L.s[u], L.r[u], L.a[u], vx, vy, vs, vr, va);
+}
+// pair energy of (u, v); d2 = squared centre distance (integer valued)
+__device__ __forceinline__ double pair_value(const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v, bool u_first,
+                                             int d2) {
+  switch (pt.kind) {
+    case MPP_P_OVERLAP: return overlap_energy_r(u.g, v.g, u_first, u.rad, v.rad, (double)d2);
+    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
+    case MPP_P_DIST_LE: return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0;
+    case MPP_P_DIST_LT: return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0;
+  }
+  return 0.0;
+}
+
+// reduction of pair term p over the neighbours of slot u, skipping `skip`, optionally including
+// an extra rectangle (the proposal's new point).  Whole wave cooperates; result is uniform.
+__device__ double rescan_point(const Chain &c, int p, int u, int skip, bool has_add, const Rect &ar, const Geo2 &ag) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const mpp_pair_term &pt = P->model.pair[p];
+  Geo2 gu = load_geo(L, u);
+  int ci, cj;
+  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
+  double acc = 0.0;                       // 0 is neutral for every supported (kind, reduce) pair
+  for (int di = -1; di <= 1; ++di)
+    for (int dj = -1; dj <= 1; ++dj) {
+      int i = ci + di, j = cj + dj;
+      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
+      int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      for (int e = c.lane; e < cnt; e += WAVE) {
+        int w = L.cell_items[cell * P->cell_cap + e];
+        if (w == u || w == skip) continue;
+        Geo2 gw = load_geo(L, w);
+        int dx = gu.g.x - gw.g.x, dy = gu.g.y - gw.g.y, d2 = dx * dx + dy * dy;
+        if (d2 <= P->maxd2[p]) {
+          bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
+          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
+        }
+      }
+    }
+  if (has_add && c.lane == 0) {
+    int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
+    if (d2 <= P->maxd2[p]) {
+      bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
+    }
+  }
+  return wave_reduce(pt.reduce, acc);
+}
+
+// the same reduction computed by ONE lane on its own (used inside eval_delta: the few lanes whose
+// neighbour loses its extremum each walk that neighbour's 3x3 cells, all of them at the same time)
+__device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int skip, bool has_add, const Rect &ar,
+                              const Geo2 &ag) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const mpp_pair_term &pt = P->model.pair[p];
+  int ci, cj;
+  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
+  double acc = 0.0;
+  for (int di = -1; di <= 1; ++di)
+    for (int dj = -1; dj <= 1; ++dj) {
+      int i = ci + di, j = cj + dj;
+      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
+      int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      for (int e = 0; e < cnt; ++e) {
+        int w = L.cell_items[cell * P->cell_cap + e];
+        if (w == u || w == skip) continue;
+        int wxy = L.xy[w];
+        int dx = gu.g.x - (wxy & 0xffff), dy = gu.g.y - ((wxy >> 16) & 0xffff), d2 = dx * dx + dy * dy;
+        if (d2 <= P->maxd2[p]) {
+          Geo2 gw = load_geo(L, w);
+          bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
+          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
+        }
+      }
+    }
+  if (has_add) {
+    int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
+    if (d2 <= P->maxd2[p]) {
+      bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
+    }
+  }
+  return acc;
+}
+
+// dE of (remove slot `rem`, add rectangle `ar`) -- energy_graph.py:139-225 -- as
+//   sum over neighbours u of [e_u(after) - e_u(before)]  +  e_added - e_removed.
+// The neighbours whose cached reductions change are written to the wave's stash
+// (slot, new0, new1) so that an accepted step is applied without re-evaluation;
+// *n_stash > STASH means the stash overflowed.  With APPLY the caches are updated directly.
+#ifdef MPP_PROFILE
+#define DPROF(i)
+__device__ unsigned long long g_prof2[16];
+#else
+#define DPROF(i)
+#endif
+template <bool APPLY>
+__device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
+                             int gate_a, double *ra0_out, double *ra1_out, int *n_stash, int *err) {
+#ifdef MPP_PROFILE
+  unsigned long long dpt_ = clock64();
+#endif
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const int np = P->model.n_pair;
+  const bool has_rem = rem >= 0;
+  Geo2 gr;
+  Rect rr;
+  if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
+  else { gr = ag; rr = ar; }
+  int cir = 0, cjr = 0, cia = 0, cja = 0;
+  if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
+  if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
+
+  // ---- the 3x3 cells around the removed and the added point: lanes 0..17 own one cell each
+  int my_cell = -1;
+  if (c.lane < 18) {
+    bool second = c.lane >= 9;
+    int k = second ? c.lane - 9 : c.lane;
+    int i = (second ? cia : cir) + k / 3 - 1, j = (second ? cja : cjr) + k % 3 - 1;
+    bool ok = second ? has_add : has_rem;
+    if (ok && second && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) ok = false;   // already listed
+    if (ok && i >= 0 && i < P->nx && j >= 0 && j < P->ny) my_cell = j + i * P->ny;
+  }
+  int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
+  // offsets of the 18 cells in the flattened candidate index space (wave-uniform, scalar registers)
+  int M = 0;
+  int my_lo = 0, my_base = 0;           // per lane j: first flattened index of its cell, LDS base of that cell
+  {
+    int lo = 0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
+      int cell_k = __builtin_amdgcn_readlane(my_cell, k);
+      if (c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+      lo += cnt_k;
+    }
+    M = lo;
+  }
+
+  DPROF(0);
+#ifdef MPP_PROFILE
+  if (c.wave == 0 && c.lane == 0) { atomicAdd(&g_prof2[9], (unsigned long long)M); atomicAdd(&g_prof2[11], 1ull); }
+#endif
+  double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
+  bool any_changed = false, any_a = false;
+  int stash_n = 0;
+  for (int base = 0; base < M; base += WAVE) {
+    if (base > 0) {                              // (rare) more than 64 candidates: find this lane's cell again
+      int lo = 0;
+      my_lo = 0; my_base = 0;
+#pragma unroll
+      for (int k = 0; k < 18; ++k) {
+        int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
+        int cell_k = __builtin_amdgcn_readlane(my_cell, k);
+        if (base + c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+        lo += cnt_k;
+      }
+    }
+    int j = base + c.lane;
+    bool active = j < M;
+    int u = active ? (int)L.cell_items[my_base + (j - my_lo)] : 0;
+    if (active && u == rem) active = false;
+    Geo2 gu;
+    double oldv[2] = {0.0, 0.0}, newv[2] = {0.0, 0.0};
+    bool slow[2] = {false, false};
+    if (active) {
+      gu = load_geo(L, u);
+      oldv[0] = L.red0[u]; oldv[1] = L.red1[u];
+      int d2r = 0, d2a = 0;
+      if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
+      if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
+      for (int p = 0; p < np; ++p) {
+        const mpp_pair_term &pt = P->model.pair[p];
+        bool in_r = has_rem && d2r <= P->maxd2[p], in_a = has_add && d2a <= P->maxd2[p];
+        double nv = oldv[p];
+        if (in_r && oldv[p] != 0.0) {
+          bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
+          double v_r = pair_value(pt, gu, gr, uf, d2r);
+          if (v_r == oldv[p]) slow[p] = true;       // the removed point carries u's extremum
+        }
+        if (in_a) {
+          bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+          double v_a = pair_value(pt, gu, ag, uf, d2a);
+          ra[p] = reduce2(pt.reduce, ra[p], v_a);
+          nv = reduce2(pt.reduce, nv, v_a);
+          any_a = true;
+        }
+        newv[p] = nv;
+      }
+    }
+    DPROF(1);
+    // the neighbours that lose their extremum are re-reduced over their own 3x3 cells
+    for (int p = 0; p < np; ++p)
+      if (slow[p]) newv[p] = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+    DPROF(2);
+    bool changed = active && ((newv[0] != oldv[0]) || (newv[1] != oldv[1]));
+    if (changed) {
+      double lin = L.lin[u];
+      int gt = L.gate[u];
+      de_acc += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
+                finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
+      any_changed = true;
+      if (APPLY) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
+    }
+    unsigned long long cm = __ballot(changed);
+    if (!APPLY && changed) {
+      int rank = stash_n + __popcll(cm & ((1ull << c.lane) - 1ull));
+      if (rank < STASH) {
+        L.stash_slot[c.wave * STASH + rank] = (unsigned short)u;
+        L.stash_v0[c.wave * STASH + rank] = newv[0];
+        L.stash_v1[c.wave * STASH + rank] = newv[1];
+      }
+    }
+    stash_n += __popcll(cm);
+  }
+  DPROF(3);
+  // combine the few lanes that contribute, in ascending lane order (deterministic, wave-uniform result)
+  double sum_de = 0.0, ra0 = 0.0, ra1 = 0.0;
+  unsigned long long cm = __ballot(any_changed);
+  while (cm) {
+    int src = __ffsll((long long)cm) - 1;
+    cm &= cm - 1;
+    sum_de += readlane_d(de_acc, src);
+  }
+  unsigned long long am = __ballot(any_a);
+  while (am) {
+    int src = __ffsll((long long)am) - 1;
+    am &= am - 1;
+    if (np > 0) ra0 = reduce2(P->model.pair[0].reduce, ra0, readlane_d(ra[0], src));
+    if (np > 1) ra1 = reduce2(P->model.pair[1].reduce, ra1, readlane_d(ra[1], src));
+  }
+  *ra0_out = ra0; *ra1_out = ra1;
+  *n_stash = stash_n;
+  (void)err;
+  double dE = sum_de;
+  if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra0, ra1));
+  if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  DPROF(4);
+  return dE;
+}
+
+// ---- proposal densities (shape_samplers.py:103-108, transform_kernels.py:94-99, :203-225) -------
+// One 32-bin mark row (128 B): every lane reads the whole row (a broadcast read of one cache line) and
+// sums it in index order -- no cross-lane traffic, wave-uniform result, same order as the oracle.
+// Returns P[cls]/sum; with `draw` the class is first drawn: #{j : cumsum_j <= u*sum}.
+__device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool draw, double u, int *drawn) {
+  const float4 *row = (const float4 *)mark_row(c.P, c.t, k, x, y);
+  float v[MPP_NCLASS];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { float4 q = row[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
+  double tot = 0.0;
+#pragma unroll
+  for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)v[i];
+  if (draw) {
+    double acc = 0.0, thr = u * tot;
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) { acc += (double)v[i]; d += (acc <= thr) ? 1 : 0; }
+    cls = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
+    *drawn = cls;
+  }
+  float pc = 0.f;
+#pragma unroll
+  for (int i = 0; i < MPP_NCLASS; ++i) pc = (i == cls) ? v[i] : pc;
+  return (double)pc / tot;
+}
+__device__ double birth_density(const Chain &c, const Rect &q) {
+  const DevParams *P = c.P;
+  double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / c.t.rowbase[P->H];
+  d *= row_prob(c, 0, q.x, q.y, value_to_class_tab(P, c.L.edges, 0, q.s), false, 0.0, nullptr);
+  d *= row_prob(c, 1, q.x, q.y, value_to_class_tab(P, c.L.edges + MPP_NCLASS, 1, q.r), false, 0.0, nullptr);
+  d *= row_prob(c, 2, q.x, q.y, value_to_class_tab(P, c.L.edges + 2 * MPP_NCLASS, 2, q.a), false, 0.0, nullptr);
+  return d * ((double)P->H * (double)P->W * 32768.0);
+}
+// data-driven translation (transform_kernels.py:77-89): draw a pixel of the (2*max_delta+1)^2 window
+// around (x,y) with probability det/sum.  Lane i owns window row i (<= 31 rows): its segment sum comes
+// from the per-row prefix table, the row is found by an ordered readlane walk, the column by a ballot.
+__device__ void window_draw(const Chain &c, int x, int y, double u, int *ex, int *ey) {
+  const DevParams *P = c.P;
+  const int md = P->kern.max_delta;
+  const int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
+  const int nrow = x1 - x0, wc = y1 - y0;
+  const double tot = c.t.boxsum[(size_t)x * P->W + y];
+  double seg = 0.0;
+  if (c.lane < nrow) {
+    const double *rp = c.t.rowpart + (size_t)(x0 + c.lane) * P->W;
+    seg = rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0);
+  }
+  double before = 0.0;          // sum of the rows above the chosen one
+  const double thr = u * tot;   // cdf <= u  <=>  partial sum <= u * total
+  int row = 0;
+  for (int i = 0; i < nrow; ++i) {
+    double nxt = before + readlane_d(seg, i);
+    if (nxt <= thr && i < nrow - 1) { before = nxt; row = i + 1; } else break;
+  }
+  const double *rp = c.t.rowpart + (size_t)(x0 + row) * P->W;
+  const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
+  bool le = false;
+  if (c.lane < wc) le = (before + (rp[y0 + c.lane] - lead)) <= thr;
+  int col = __popcll(__ballot(le));
+  if (col >= wc) col = wc - 1;
+  *ex = x0 + row; *ey = y0 + col;
+}
+__device__ __forceinline__ double normal_pdf(double x, double sigma) {
+  return exp(-(x * x) / (2.0 * sigma * sigma)) / (sigma * sqrt(MPP_TWO_PI));
+}
+__device__ void box_muller(uint32_t a, uint32_t b, double *z0, double *z1) {
+  double u1 = ((double)a + 1.0) * (1.0 / 4294967296.0), u2 = u32d(b);
+  double r = sqrt(-2.0 * log(u1)), th = MPP_TWO_PI * u2;
+  *z0 = r * cos(th); *z1 = r * sin(th);
+}
+__device__ double wrap_mark(const DevParams *P, int k, double v) {
+  double lo = P->maps.vmin[k], hi = P->maps.vmax[k];
+  if (P->maps.cyclic[k]) {
+    double range = hi - lo, m = fmod(v, range);
+    if (m < 0) m += range;
+    return m + lo;
+  }
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+
+
+// =====================================================================================================
+// Lane mode: ONE LANE evaluates one speculative step completely on its own -- no cross-lane traffic.
+// A wave instruction costs the same with 1 or 64 active lanes, and one dependent float64 chain cannot
+// use more than one SIMD, so the steps of a round are spread over the lanes of four waves (= the four
+// SIMDs of the CU).  The arithmetic (and its order) is the one of the wave-cooperative functions above,
+// so both modes produce byte-identical chains.
+// =====================================================================================================
+__device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add, const Rect &ar, const Geo2 &ag,
+                                  double lin_a, int gate_a, double *ra0_out, double *ra1_out, int *n_stash) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const int np = P->model.n_pair;
+  const bool has_rem = rem >= 0;
+  Geo2 gr;
+  Rect rr;
+  if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
+  else { gr = ag; rr = ar; }
+  int cir = 0, cjr = 0, cia = 0, cja = 0;
+  if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
+  if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
+  double sum_de = 0.0, ra[2] = {0.0, 0.0};
+  int stash_n = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 0 ? !has_rem : !has_add) continue;
+    const int ci0 = pass == 0 ? cir : cia, cj0 = pass == 0 ? cjr : cja;
+    for (int k = 0; k < 9; ++k) {
+      int i = ci0 + k / 3 - 1, j = cj0 + k % 3 - 1;
+      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
+      if (pass == 1 && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) continue;     // already visited
+      const int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      for (int e = 0; e < cnt; ++e) {
+        const int u = L.cell_items[cell * P->cell_cap + e];
+        if (u == rem) continue;
+        const int uxy = L.xy[u];
+        const int ux = uxy & 0xffff, uy = (uxy >> 16) & 0xffff;
+        int d2r = 0, d2a = 0;
+        if (has_rem) { int dx = ux - gr.g.x, dy = uy - gr.g.y; d2r = dx * dx + dy * dy; }
+        if (has_add) { int dx = ux - ag.g.x, dy = uy - ag.g.y; d2a = dx * dx + dy * dy; }
+        bool touch = false;
+        for (int p = 0; p < np; ++p)
+          touch |= (has_rem && d2r <= P->maxd2[p]) || (has_add && d2a <= P->maxd2[p]);
+        if (!touch) continue;                    // too far to interact with either point
+        Geo2 gu = load_geo(L, u);
+        double oldv[2] = {L.red0[u], L.red1[u]}, newv[2];
+        newv[0] = oldv[0]; newv[1] = oldv[1];
+        for (int p = 0; p < np; ++p) {
+          const mpp_pair_term &pt = P->model.pair[p];
+          bool in_r = has_rem && d2r <= P->maxd2[p], in_a = has_add && d2a <= P->maxd2[p];
+          double nv = oldv[p];
+          bool slow = false;
+          if (in_r && oldv[p] != 0.0) {
+            bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
+            if (pair_value(pt, gu, gr, uf, d2r) == oldv[p]) slow = true;     // the removed point carries u's extremum
+          }
+          if (in_a) {
+            bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+            double v_a = pair_value(pt, gu, ag, uf, d2a);
+            ra[p] = reduce2(pt.reduce, ra[p], v_a);
+            nv = reduce2(pt.reduce, nv, v_a);
+          }
+          if (slow) nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+          newv[p] = nv;
+        }
+        if (newv[0] != oldv[0] || newv[1] != oldv[1]) {
+          double lin = L.lin[u];
+          int gt = L.gate[u];
+          sum_de += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
+                    finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
+          if (stash_n < STASH) {
+            L.stash_slot[ri * STASH + stash_n] = (unsigned short)u;
+            L.stash_v0[ri * STASH + stash_n] = newv[0];
+            L.stash_v1[ri * STASH + stash_n] = newv[1];
+          }
+          ++stash_n;
+        }
+      }
+    }
+  }
+  *ra0_out = ra[0]; *ra1_out = ra[1];
+  *n_stash = stash_n;
+  double dE = sum_de;
+  if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra[0], ra[1]));
+  if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  return dE;
+}
+
+// #{i in [0,n) : key(i) <= u} for a non-decreasing key, by repeated 8-way splitting (7 independent loads
+// per level instead of a chain of log2(n) dependent ones)
+template <typename F>
+__device__ int count_le_8ary(int n, F key_le) {
+  int lo = 0, hi = n;                 // invariant: all i < lo satisfy key<=u, all i >= hi do not
+  while (hi - lo > 8) {
+    int step = (hi - lo) >> 3, c = 0;
+#pragma unroll
+    for (int j = 1; j <= 7; ++j) c += key_le(lo + j * step - 1) ? 1 : 0;
+    int nlo = lo + c * step;          // probes are at lo+step-1, lo+2step-1, ...: c of them are <= u
+    hi = c < 7 ? lo + (c + 1) * step - 1 : hi;
+    lo = nlo;
+  }
+  int c = lo;
+  for (int i = lo; i < hi; ++i) c += key_le(i) ? 1 : 0;
+  return c;
+}
+
+__device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex, int *ey) {
+  const DevParams *P = c.P;
+  const int md = P->kern.max_delta;
+  const int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
+  const int nrow = x1 - x0, wc = y1 - y0;
+  const double tot = c.t.boxsum[(size_t)x * P->W + y];
+  double before = 0.0;
+  const double thr = u * tot;
+  int row = 0;
+  for (int i = 0; i < nrow; ++i) {
+    const double *rp = c.t.rowpart + (size_t)(x0 + i) * P->W;
+    double nxt = before + (rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0));
+    if (nxt <= thr && i < nrow - 1) { before = nxt; row = i + 1; } else break;
+  }
+  const double *rp = c.t.rowpart + (size_t)(x0 + row) * P->W;
+  const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
+  int col = 0;
+  for (int jj = 0; jj < wc; ++jj) col += ((before + (rp[y0 + jj] - lead)) <= thr) ? 1 : 0;
+  if (col >= wc) col = wc - 1;
+  *ex = x0 + row; *ey = y0 + col;
+}
+
+// which parts of the target's cached geometry survive the proposal
+#define KEEP_TRIG 1
+#define KEEP_SIZE 2
+#define KEEP_QF 4             // the forward density was computed while drawing (data-driven birth)
+
+// draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
+template <bool LANE>
+__device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &r, int *keep) {
+  const DevParams *P = c.P;
+  double uk = u53(w[0], w[1]);
+  int k = 0;
+  while (k < MPP_NKERNEL - 1 && P->p_cum[k] <= uk) ++k;
+  r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1;
+  r.aux0 = r.aux1 = 0.0; r.ax = r.ay = 0; r.as = r.ar = r.aa = 0.0; r.rx = r.ry = 0;
+  r.u_acc = u53(w[10], w[11]);
+  *keep = 0;
+  if (k == MPP_K_UBIRTH) {
+    r.has_add = 1;
+    r.ax = (int)mulhi32(w[3], (uint32_t)P->H); r.ay = (int)mulhi32(w[4], (uint32_t)P->W);
+    r.as = P->maps.vmin[0] + (P->maps.vmax[0] - P->maps.vmin[0]) * u32d(w[5]);
+    r.ar = P->maps.vmin[1] + (P->maps.vmax[1] - P->maps.vmin[1]) * u32d(w[6]);
+    r.aa = P->maps.vmin[2] + (P->maps.vmax[2] - P->maps.vmin[2]) * u32d(w[7]);
+    return;
+  }
+  if (k == MPP_K_DBIRTH) {
+    r.has_add = 1;
+    const double u = u53(w[3], w[4]), tot = c.t.rowbase[P->H], thr = u * tot;   // cdf <= u <=> partial sum <= u*total
+    int row = 0, col = 0;                             // #rows / #columns whose inclusive cdf is <= u (monotone)
+    if (LANE) {
+      const double *rb = c.L.rowbase ? c.L.rowbase : c.t.rowbase;
+      row = count_le_8ary(P->H, [&](int i) { return rb[i + 1] <= thr; });
+      if (row >= P->H) row = P->H - 1;
+      const double base = rb[row];
+      const double *part = c.t.rowpart + (size_t)row * P->W;
+      col = count_le_8ary(P->W, [&](int j) { return (base + part[j]) <= thr; });
+    } else {
+      for (int i0 = 0; i0 < P->H; i0 += WAVE) {
+        int i = i0 + c.lane;
+        row += __popcll(__ballot(i < P->H && c.t.rowbase[i + 1] <= thr));
+      }
+      if (row >= P->H) row = P->H - 1;
+      const double base = c.t.rowbase[row];
+      const double *part = c.t.rowpart + (size_t)row * P->W;
+      for (int j0 = 0; j0 < P->W; j0 += WAVE) {
+        int j = j0 + c.lane;
+        col += __popcll(__ballot(j < P->W && (base + part[j]) <= thr));
+      }
+    }
+    if (col >= P->W) col = P->W - 1;
+    r.ax = row; r.ay = col;
+    int cls;
+    double p0 = row_prob(c, 0, row, col, 0, true, u32d(w[5]), &cls); r.as = c.L.edges[cls];
+    double p1 = row_prob(c, 1, row, col, 0, true, u32d(w[6]), &cls); r.ar = c.L.edges[MPP_NCLASS + cls];
+    double p2 = row_prob(c, 2, row, col, 0, true, u32d(w[7]), &cls); r.aa = c.L.edges[2 * MPP_NCLASS + cls];
+    // birth density of the drawn point (shape_samplers.py:103-108), same operation order as birth_density()
+    double d = (double)c.t.det[(size_t)row * P->W + col] / tot;
+    d *= p0; d *= p1; d *= p2;
+    r.qf = d * ((double)P->H * (double)P->W * 32768.0);
+    *keep = KEEP_QF;
+    return;
+  }
+  if (n == 0) return;
+  r.tidx = (int)mulhi32(w[2], (uint32_t)n);
+  r.tslot = c.L.order[r.tidx];
+  r.has_rem = 1;
+  Rect q = load_rect(c.L, r.tslot);
+  r.rx = q.x; r.ry = q.y;
+  if (k == MPP_K_UDEATH || k == MPP_K_DDEATH) return;
+  r.has_add = 1;
+  if (k == MPP_K_GTRANS) {
+    double z0, z1;
+    box_muller(w[3], w[4], &z0, &z1);
+    double d0 = P->kern.sigma_trans * z0, d1 = P->kern.sigma_trans * z1;
+    int nx = (int)((double)q.x + d0), ny = (int)((double)q.y + d1);
+    q.x = min(max(nx, 0), P->H - 1); q.y = min(max(ny, 0), P->W - 1);
+    r.aux0 = d0; r.aux1 = d1;
+    *keep = KEEP_TRIG | KEEP_SIZE;
+  } else if (k == MPP_K_DTRANS) {
+    int ex, ey;
+    if (LANE) window_draw_lane(c, q.x, q.y, u53(w[3], w[4]), &ex, &ey);
+    else window_draw(c, q.x, q.y, u53(w[3], w[4]), &ex, &ey);
+    q.x = ex; q.y = ey;
+    *keep = KEEP_TRIG | KEEP_SIZE;
+  } else if (k == MPP_K_GTRANSF) {
+    int pid = (int)mulhi32(w[3], 3u);
+    double z0, z1;
+    box_muller(w[4], w[5], &z0, &z1);
+    double d = P->kern.sigma_transform * (P->maps.vmax[pid] - P->maps.vmin[pid]) * z0;
+    set_mark(q, pid, wrap_mark(P, pid, mark_of(q, pid) + d));
+    r.pid = pid; r.aux0 = d;
+    *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
+  } else {
+    int pid = (int)mulhi32(w[3], 3u), cls;
+    row_prob(c, pid, q.x, q.y, 0, true, u32d(w[4]), &cls);
+    set_mark(q, pid, c.L.edges[pid * MPP_NCLASS + cls]);
+    r.pid = pid; r.ncls = cls;
+    *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
+  }
+  r.ax = q.x; r.ay = q.y; r.as = q.s; r.ar = q.r; r.aa = q.a;
+}
+
+// n-independent parts of the forward / backward proposal probabilities.  The symmetric Gaussian
+// kernels have qf == qb, which cancels in the Green ratio: their pdf is evaluated only for traces.
+__device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep) {
+  const DevParams *P = c.P;
+  if (keep & KEEP_QF) { r.qb = 1.0; return; }
+  r.qf = 1.0; r.qb = 1.0;
+  Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
+  switch (r.kernel) {
+    case MPP_K_DBIRTH: r.qf = birth_density(c, add); break;
+    case MPP_K_DDEATH:
+      if (r.has_rem) r.qb = birth_density(c, load_rect(c.L, r.tslot));
+      break;
+    case MPP_K_GTRANS:
+      if (r.has_rem && tracing)
+        r.qf = r.qb = normal_pdf(r.aux0, P->kern.sigma_trans) * normal_pdf(r.aux1, P->kern.sigma_trans);
+      break;
+    case MPP_K_DTRANS:
+      if (r.has_rem) {        // transform_kernels.py:94-99: window renormalised around start resp. end
+        r.qf = (double)c.t.det[(size_t)r.ax * P->W + r.ay] / c.t.boxsum[(size_t)r.rx * P->W + r.ry];
+        r.qb = (double)c.t.det[(size_t)r.rx * P->W + r.ry] / c.t.boxsum[(size_t)r.ax * P->W + r.ay];
+      }
+      break;
+    case MPP_K_GTRANSF:
+      if (r.has_rem && tracing)
+        r.qf = r.qb = normal_pdf(r.aux0, P->kern.sigma_transform * (P->maps.vmax[r.pid] - P->maps.vmin[r.pid]));
+      break;
+    case MPP_K_DTRANSF:
+      if (r.has_rem) {
+        Rect old = load_rect(c.L, r.tslot);
+        int oc = value_to_class_tab(P, c.L.edges + r.pid * MPP_NCLASS, r.pid, mark_of(old, r.pid));
+        const float *row = mark_row(P, c.t, r.pid, old.x, old.y);
+        // both classes of the same row: P[new]/sum and P[old]/sum (one row read)
+        double tot = 0.0;
+        for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)row[i];
+        r.qf = (double)row[r.ncls] / tot;
+        r.qb = (double)row[oc] / tot;
+      }
+      break;
+    default: break;
+  }
+}
+
+// base_kernels.py:55-64,100-115 ; transform_kernels.py forward/backward_probability
+__device__ __forceinline__ void green_terms(const DevParams *P, const Rec &r, int n, double intensity, double *fwd,
+                                            double *bwd) {
+  const double *pk = P->kern.p_kernel;
+  int k = r.kernel;
+  if (k == MPP_K_UBIRTH || k == MPP_K_DBIRTH) {
+    *fwd = pk[k] * r.qf / intensity; *bwd = pk[k + 1] / (double)(n + 1);
+  } else if (!r.has_rem) {
+    *fwd = pk[k]; *bwd = pk[k];
+  } else if (k == MPP_K_UDEATH || k == MPP_K_DDEATH) {
+    *fwd = pk[k] / (double)n; *bwd = pk[k - 1] * r.qb / intensity;
+  } else {
+    *fwd = pk[k] * r.qf / (double)n; *bwd = pk[k] * r.qb / (double)n;
+  }
+}
+
+// ---- state mutation (energy_point_set.py:118-154), wave 0 only ----------------------------------
+__device__ void cell_remove(const Chain &c, int cell, int slot) {
+  const Lds &L = c.L;
+  int cnt = L.cell_cnt[cell];
+  unsigned short *it = L.cell_items + (size_t)cell * c.P->cell_cap;
+  unsigned long long m = __ballot(c.lane < cnt && it[c.lane] == slot);
+  wave_lds_fence();
+  if (m && c.lane == 0) {
+    int idx = __ffsll((long long)m) - 1;
+    it[idx] = it[cnt - 1];
+    L.cell_cnt[cell] = (unsigned short)(cnt - 1);
+  }
+  wave_lds_fence();
+}
+__device__ void cell_insert(const Chain &c, int cell, int slot, int *err) {
+  const Lds &L = c.L;
+  int cnt = L.cell_cnt[cell];
+  if (cnt >= c.P->cell_cap) { *err = ERR_CELL_OVERFLOW; return; }
+  if (c.lane == 0) {
+    L.cell_items[(size_t)cell * c.P->cell_cap + cnt] = (unsigned short)slot;
+    L.cell_cnt[cell] = (unsigned short)(cnt + 1);
+  }
+  wave_lds_fence();
+}
+__device__ void write_slot(const Chain &c, int slot, const Rec &q) {
+  const Lds &L = c.L;
+  if (c.lane == 0) {
+    L.xy[slot] = (q.ax & 0xffff) | (q.ay << 16);
+    L.s[slot] = q.as; L.r[slot] = q.ar; L.a[slot] = q.aa;
+    L.ca[slot] = q.ca; L.sa[slot] = q.sa; L.hl[slot] = q.hl; L.hw[slot] = q.hw; L.rad[slot] = q.rad;
+    L.lin[slot] = q.lin_a; L.gate[slot] = (unsigned char)q.gate_a; L.red0[slot] = q.ra0; L.red1[slot] = q.ra1;
+  }
+}
+
+// evaluate one step completely (everything but the state mutation): proposal geometry, unit energy,
+// dE, and the accept decision for population n at temperature T
+#ifdef MPP_PROFILE
+#define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
+template <bool LANE>
+__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, int *err,
+                         unsigned long long *prof) {
+  unsigned long long pt_ = clock64();
+#else
+#define EPROF(i)
+template <bool LANE>
+__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, int *err) {
+#endif
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  proposal_densities(c, r, tracing, keep);
+  EPROF(4);
+  r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
+  r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
+  if (r.has_rem || r.has_add) {
+    Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
+    Geo2 ag;
+    ag.g.x = add.x; ag.g.y = add.y; ag.g.hl = ag.g.hw = ag.g.ca = ag.g.sa = 0.0; ag.rad = 0.0;
+    if (r.has_add) {
+      if (keep & KEEP_SIZE) { ag.g.hl = L.hl[r.tslot]; ag.g.hw = L.hw[r.tslot]; ag.rad = L.rad[r.tslot]; }
+      else {
+        double length = (2.0 * add.s) / (1.0 + add.r), width = add.r * length;
+        ag.g.hl = length / 2.0; ag.g.hw = width / 2.0;
+        ag.rad = geo_radius(ag.g);
+      }
+      if (keep & KEEP_TRIG) { ag.g.ca = L.ca[r.tslot]; ag.g.sa = L.sa[r.tslot]; }
+      else { double al = add.a + MPP_PI / 2.0; ag.g.ca = cos(al); ag.g.sa = sin(al); }
+      EPROF(5);
+      unit_part(P, c.t, L.edges, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
+      r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;
+      EPROF(6);
+    }
+    if (LANE)
+      r.dE = eval_delta_lane(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+                             &r.n_stash);
+    else
+      r.dE = eval_delta<false>(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+                               &r.n_stash, err);
+    EPROF(7);
+  }
+  double fwd, bwd;
+  green_terms(P, r, n, c.t.intensity, &fwd, &bwd);
+  // rjmcmc.py:105-113: accept <=> log(u+eps) < -dE/T + log(bwd+eps) - log(fwd+eps)
+  //                           <=> u+eps < exp(-dE/T) * (bwd+eps)/(fwd+eps)      (one exp instead of three logs)
+  double ratio = (bwd + EPS_GREEN) / (fwd + EPS_GREEN);
+  r.accepted = (P->force_accept || (r.u_acc + EPS_GREEN) < exp(-r.dE / T) * ratio) ? 1 : 0;
+  if (tracing) { r.fwd = fwd; r.bwd = bwd; r.log_alpha = (-r.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN); }
+  EPROF(8);
+}
+

@@ -169,7 +169,7 @@ class MppContext:
     """One GPU context holding ``n_tiles`` tiles of equal shape (thin, 1:1 over the C ABI)."""
 
     def __init__(self, device: int = 0, point_capacity: Optional[int] = None, cell_capacity: Optional[int] = None,
-                 spec_waves: Optional[int] = None):
+                 spec_waves: Optional[int] = None, spec_lanes: Optional[int] = None):
         self._L = load_library()
         h = C.c_void_p()
         rc = self._L.mpp_create(int(device), C.byref(h))
@@ -187,6 +187,8 @@ class MppContext:
             self.set_option("cell_capacity", cell_capacity)
         if spec_waves is not None:
             self.set_option("spec_waves", spec_waves)
+        if spec_lanes is not None:
+            self.set_option("spec_lanes", spec_lanes)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):

@@ -13,7 +13,7 @@ from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings, synth
 pytestmark = pytest.mark.gpu
 
 
-def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512):
+def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, lanes=0):
     t = synth.make_tile(tile, n_obj, tile_id=tile_id, noise=noise)
     setup, comb, model = model_for(setup_name)
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kernels.make_kernels(mappings.default_mappings(), 1.0))
@@ -21,7 +21,7 @@ def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512):
     kd = kernels.make_kernels(mappings.default_mappings(), max(1, len(xy)))
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kd)
     o.set_points(xy, marks)
-    ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec)
+    ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec, spec_lanes=lanes)
     ctx.set_maps(t.det, t.marks)
     ctx.set_model(model, mappings.default_mappings())
     ctx.set_kernels(kd)
@@ -73,6 +73,24 @@ def test_speculative_waves_reproduce_the_sequential_chain(spec):
     xy1, m1 = c1.get_points()
     xys, ms = cs.get_points()
     assert xy1.tobytes() == xys.tobytes() and m1.tobytes() == ms.tobytes()
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("setup_name", ["legacy", "no-calibration"])
+def test_lane_mode_reproduces_the_sequential_chain(lanes, setup_name):
+    """One lane per speculative step (4 waves x `lanes` lanes): byte-identical to the one-wave kernel."""
+    n_steps, seed = 8000, 11
+    t, o, c1 = setup_case(128, 40, setup_name, spec=1)
+    _, _, cl = setup_case(128, 40, setup_name, lanes=lanes)
+    for c in (c1, cl):
+        c.set_schedule(1.0, 0.9985, 0.0)
+    out1, props1 = c1.run(n_steps, seed, trace_tile=0)
+    outl, propsl = cl.run(n_steps, seed, trace_tile=0)
+    assert props1.tobytes() == propsl.tobytes()
+    assert out1.tobytes() == outl.tobytes()
+    xy1, m1 = c1.get_points()
+    xyl, ml = cl.get_points()
+    assert xy1.tobytes() == xyl.tobytes() and m1.tobytes() == ml.tobytes()
 
 
 def test_chain_in_two_launches_equals_one_launch():

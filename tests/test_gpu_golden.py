@@ -14,7 +14,10 @@ ORC_ATOL = 1e-9                                   # vs the float64 oracle
 
 
 def make_ctx(t: Tape, spec=1):
-    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec)
+    lanes = 0
+    if isinstance(spec, str):                       # "L4": lane mode, 4 waves x 4 lanes
+        lanes, spec = int(spec[1:]), 1
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec, spec_lanes=lanes)
     ctx.set_maps(t.det, t.marks)
     ctx.set_model(t.model, mappings.default_mappings())
     ctx.set_kernels(t.kernels)
@@ -22,7 +25,7 @@ def make_ctx(t: Tape, spec=1):
     return ctx
 
 
-@pytest.mark.parametrize("spec", [1, 4, 8])
+@pytest.mark.parametrize("spec", [1, 4, 8, "L4", "L8"])
 @pytest.mark.parametrize("name", TAPES)
 def test_tape_replay(name, spec):
     t = Tape(name)
