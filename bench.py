@@ -57,6 +57,10 @@ def main():
     ap.add_argument("--tiles-per-gpu", type=int, default=1)
     ap.add_argument("--cpu-baseline-chains", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batched-tiles", type=int, default=0,
+                    help="extra, untimed-in-`value` measurement: this many 256x256 tiles (the reference's tile size, "
+                         "50 objects, mpp_hrcM schedule of 30257 steps) sampled concurrently, one workgroup per tile")
+    ap.add_argument("--batched-spec", type=int, default=2)
     args = ap.parse_args()
 
     import torch
@@ -154,6 +158,39 @@ def main():
             "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
         },
     }
+
+    if rank == 0 and world == 1 and args.batched_tiles > 0:
+        B, bt, bobj, biters = args.batched_tiles, 256, 50, 30257
+        base = [synth.make_tile(bt, bobj, tile_id=1000 + i) for i in range(min(B, 8))]
+        reps = (B + len(base) - 1) // len(base)
+        bdet = np.concatenate([np.stack([t.det for t in base])] * reps)[:B]
+        bmarks = [np.concatenate([np.stack([t.marks[k] for t in base])] * reps)[:B] for k in range(3)]
+        bctx = hip_api.MppContext(local, point_capacity=256, spec_waves=args.batched_spec)
+        bctx.set_maps(bdet, bmarks)
+        del bdet, bmarks
+        bctx.set_model(model, maps)
+        bctx.naive_init(setup.detection_threshold, 6.0)
+        binten = np.array([max(1, bctx.count(i)) for i in range(B)], dtype=np.float64)
+        bctx.set_kernels(kernels.make_kernels(maps, 1.0), intensity=binten)
+        bctx.set_schedule(T0, alpha, Tt)
+        bctx.run(2000, seed=1)                                        # warm-up
+        bctx.naive_init(setup.detection_threshold, 6.0)
+        bctx.set_schedule(T0, alpha, Tt)
+        tb = time.perf_counter()
+        bctx.run(biters, seed=2)
+        wall = time.perf_counter() - tb
+        kms = bctx.last_kernel_ms()
+        n_end = np.array([bctx.count(i) for i in range(B)])
+        brate = B * biters / (kms * 1e-3)
+        bbpp = bytes_per_proposal(float(n_end.mean()), (bt // 32) ** 2, acc)
+        result["batched"] = {
+            "tiles": B, "tile": bt, "objects": bobj, "iters": biters, "spec_waves": args.batched_spec,
+            "proposals_per_s": brate, "kernel_ms": kms, "wall_s": wall, "mean_final_points": float(n_end.mean()),
+            "roofline": {"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS},
+            "note": "one workgroup per tile, all tiles in one launch; the reference's own parallel axis",
+        }
+        bctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle                     # the CPU restatement, timed as the baseline ("port")

@@ -25,7 +25,7 @@
 #pragma once
 #include "mpp_device.hpp"
 
-#define STASH 24              // neighbour updates remembered per speculative step
+#define STASH 32              // neighbour updates remembered per speculative step
 #define ERR_CELL_OVERFLOW 1
 #define ERR_POINT_OVERFLOW 2
 #define ERR_BAD_TARGET 3
@@ -169,44 +169,9 @@ __device__ __forceinline__ double pair_value(const mpp_pair_term &pt, const Geo2
   return 0.0;
 }
 
-// reduction of pair term p over the neighbours of slot u, skipping `skip`, optionally including
-// an extra rectangle (the proposal's new point).  Whole wave cooperates; result is uniform.
-__device__ double rescan_point(const Chain &c, int p, int u, int skip, bool has_add, const Rect &ar, const Geo2 &ag) {
-  const DevParams *P = c.P;
-  const Lds &L = c.L;
-  const mpp_pair_term &pt = P->model.pair[p];
-  Geo2 gu = load_geo(L, u);
-  int ci, cj;
-  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
-  double acc = 0.0;                       // 0 is neutral for every supported (kind, reduce) pair
-  for (int di = -1; di <= 1; ++di)
-    for (int dj = -1; dj <= 1; ++dj) {
-      int i = ci + di, j = cj + dj;
-      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
-      int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
-      for (int e = c.lane; e < cnt; e += WAVE) {
-        int w = L.cell_items[cell * P->cell_cap + e];
-        if (w == u || w == skip) continue;
-        Geo2 gw = load_geo(L, w);
-        int dx = gu.g.x - gw.g.x, dy = gu.g.y - gw.g.y, d2 = dx * dx + dy * dy;
-        if (d2 <= P->maxd2[p]) {
-          bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
-          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
-        }
-      }
-    }
-  if (has_add && c.lane == 0) {
-    int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
-    if (d2 <= P->maxd2[p]) {
-      bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
-      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
-    }
-  }
-  return wave_reduce(pt.reduce, acc);
-}
-
-// the same reduction computed by ONE lane on its own (used inside eval_delta: the few lanes whose
-// neighbour loses its extremum each walk that neighbour's 3x3 cells, all of them at the same time)
+// reduction of pair term p over the neighbours of slot u (skipping `skip`, optionally including the
+// proposal's new rectangle), computed by ONE lane on its own: inside eval_delta the few lanes whose
+// neighbour loses its extremum each walk that neighbour's 3x3 cells, all of them at the same time
 __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int skip, bool has_add, const Rect &ar,
                               const Geo2 &ag) {
   const DevParams *P = c.P;
@@ -253,12 +218,10 @@ __device__ unsigned long long g_prof2[16];
 #else
 #define DPROF(i)
 #endif
-template <bool APPLY>
+// `apply`: write the changed reductions straight into the caches instead of the stash (used for the rare
+// step whose neighbour updates do not fit the stash; see the kernel's "apply round").
 __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
-                             int gate_a, double *ra0_out, double *ra1_out, int *n_stash, int *err) {
-#ifdef MPP_PROFILE
-  unsigned long long dpt_ = clock64();
-#endif
+                             int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
   const int np = P->model.n_pair;
@@ -281,89 +244,76 @@ __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &
     if (ok && second && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) ok = false;   // already listed
     if (ok && i >= 0 && i < P->nx && j >= 0 && j < P->ny) my_cell = j + i * P->ny;
   }
-  int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
-  // offsets of the 18 cells in the flattened candidate index space (wave-uniform, scalar registers)
+  const int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
+  // flattened candidate index space: cell k covers [lo_k, lo_k + cnt_k)  (wave-uniform, scalar registers)
   int M = 0;
-  int my_lo = 0, my_base = 0;           // per lane j: first flattened index of its cell, LDS base of that cell
-  {
-    int lo = 0;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
-      int cell_k = __builtin_amdgcn_readlane(my_cell, k);
-      if (c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
-      lo += cnt_k;
-    }
-    M = lo;
-  }
+  for (int k = 0; k < 18; ++k) M += __builtin_amdgcn_readlane(my_cnt, k);
 
-  DPROF(0);
-#ifdef MPP_PROFILE
-  if (c.wave == 0 && c.lane == 0) { atomicAdd(&g_prof2[9], (unsigned long long)M); atomicAdd(&g_prof2[11], 1ull); }
-#endif
   double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
   bool any_changed = false, any_a = false;
   int stash_n = 0;
   for (int base = 0; base < M; base += WAVE) {
-    if (base > 0) {                              // (rare) more than 64 candidates: find this lane's cell again
-      int lo = 0;
-      my_lo = 0; my_base = 0;
+    const int j = base + c.lane;
+    int my_lo = 0, my_base = 0, lo = 0;
 #pragma unroll
-      for (int k = 0; k < 18; ++k) {
-        int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
-        int cell_k = __builtin_amdgcn_readlane(my_cell, k);
-        if (base + c.lane >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
-        lo += cnt_k;
-      }
+    for (int k = 0; k < 18; ++k) {
+      int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
+      int cell_k = __builtin_amdgcn_readlane(my_cell, k);
+      if (j >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+      lo += cnt_k;
     }
-    int j = base + c.lane;
     bool active = j < M;
-    int u = active ? (int)L.cell_items[my_base + (j - my_lo)] : 0;
+    const int u = active ? (int)L.cell_items[my_base + (j - my_lo)] : 0;
     if (active && u == rem) active = false;
     Geo2 gu;
     double oldv[2] = {0.0, 0.0}, newv[2] = {0.0, 0.0};
-    bool slow[2] = {false, false};
     if (active) {
       gu = load_geo(L, u);
       oldv[0] = L.red0[u]; oldv[1] = L.red1[u];
       int d2r = 0, d2a = 0;
       if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
       if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
+#pragma clang loop unroll(disable)
       for (int p = 0; p < np; ++p) {
         const mpp_pair_term &pt = P->model.pair[p];
-        bool in_r = has_rem && d2r <= P->maxd2[p], in_a = has_add && d2a <= P->maxd2[p];
-        double nv = oldv[p];
-        if (in_r && oldv[p] != 0.0) {
-          bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
-          double v_r = pair_value(pt, gu, gr, uf, d2r);
-          if (v_r == oldv[p]) slow[p] = true;       // the removed point carries u's extremum
+        const double ov = p == 0 ? oldv[0] : oldv[1];
+        double nv = ov;
+        bool slow = false;
+        // which = 0: against the removed point (is it the one carrying u's extremum?)
+        // which = 1: against the added point (it may become u's new extremum)
+#pragma clang loop unroll(disable)
+        for (int which = 0; which < 2; ++which) {
+          const bool in = which == 0 ? (has_rem && d2r <= P->maxd2[p] && ov != 0.0) : (has_add && d2a <= P->maxd2[p]);
+          if (!in) continue;
+          const Geo2 gv = which == 0 ? gr : ag;
+          const Rect rv = which == 0 ? rr : ar;
+          const bool uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
+          const double v = pair_value(pt, gu, gv, uf, which == 0 ? d2r : d2a);
+          if (which == 0) slow = (v == ov);
+          else {
+            double &rap = p == 0 ? ra[0] : ra[1];
+            rap = reduce2(pt.reduce, rap, v);
+            nv = reduce2(pt.reduce, nv, v);
+            any_a = true;
+          }
         }
-        if (in_a) {
-          bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
-          double v_a = pair_value(pt, gu, ag, uf, d2a);
-          ra[p] = reduce2(pt.reduce, ra[p], v_a);
-          nv = reduce2(pt.reduce, nv, v_a);
-          any_a = true;
-        }
-        newv[p] = nv;
+        // a neighbour that loses its extremum is re-reduced over its own 3x3 cells (in its lane)
+        if (slow) nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+        if (p == 0) newv[0] = nv; else newv[1] = nv;
       }
     }
-    DPROF(1);
-    // the neighbours that lose their extremum are re-reduced over their own 3x3 cells
-    for (int p = 0; p < np; ++p)
-      if (slow[p]) newv[p] = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
-    DPROF(2);
-    bool changed = active && ((newv[0] != oldv[0]) || (newv[1] != oldv[1]));
+    const bool changed = active && ((newv[0] != oldv[0]) || (newv[1] != oldv[1]));
     if (changed) {
       double lin = L.lin[u];
       int gt = L.gate[u];
       de_acc += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
                 finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
       any_changed = true;
-      if (APPLY) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
+      if (apply) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
     }
-    unsigned long long cm = __ballot(changed);
-    if (!APPLY && changed) {
+    const unsigned long long cm = __ballot(changed);
+    if (!apply && changed) {
       int rank = stash_n + __popcll(cm & ((1ull << c.lane) - 1ull));
       if (rank < STASH) {
         L.stash_slot[c.wave * STASH + rank] = (unsigned short)u;
@@ -373,7 +323,6 @@ __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &
     }
     stash_n += __popcll(cm);
   }
-  DPROF(3);
   // combine the few lanes that contribute, in ascending lane order (deterministic, wave-uniform result)
   double sum_de = 0.0, ra0 = 0.0, ra1 = 0.0;
   unsigned long long cm = __ballot(any_changed);
@@ -391,11 +340,9 @@ __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &
   }
   *ra0_out = ra0; *ra1_out = ra1;
   *n_stash = stash_n;
-  (void)err;
   double dE = sum_de;
   if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra0, ra1));
   if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
-  DPROF(4);
   return dE;
 }
 
@@ -427,9 +374,9 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
 __device__ double birth_density(const Chain &c, const Rect &q) {
   const DevParams *P = c.P;
   double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / c.t.rowbase[P->H];
-  d *= row_prob(c, 0, q.x, q.y, value_to_class_tab(P, c.L.edges, 0, q.s), false, 0.0, nullptr);
-  d *= row_prob(c, 1, q.x, q.y, value_to_class_tab(P, c.L.edges + MPP_NCLASS, 1, q.r), false, 0.0, nullptr);
-  d *= row_prob(c, 2, q.x, q.y, value_to_class_tab(P, c.L.edges + 2 * MPP_NCLASS, 2, q.a), false, 0.0, nullptr);
+#pragma clang loop unroll(disable)
+  for (int k = 0; k < 3; ++k)
+    d *= row_prob(c, k, q.x, q.y, value_to_class_tab(P, c.L.edges + k * MPP_NCLASS, k, mark_of(q, k)), false, 0.0, nullptr);
   return d * ((double)P->H * (double)P->W * 32768.0);
 }
 // data-driven translation (transform_kernels.py:77-89): draw a pixel of the (2*max_delta+1)^2 window
@@ -488,7 +435,7 @@ __device__ double wrap_mark(const DevParams *P, int k, double v) {
 // so both modes produce byte-identical chains.
 // =====================================================================================================
 __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add, const Rect &ar, const Geo2 &ag,
-                                  double lin_a, int gate_a, double *ra0_out, double *ra1_out, int *n_stash) {
+                                  double lin_a, int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
   const int np = P->model.n_pair;
@@ -548,7 +495,8 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
           int gt = L.gate[u];
           sum_de += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
                     finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
-          if (stash_n < STASH) {
+          if (apply) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
+          else if (stash_n < STASH) {
             L.stash_slot[ri * STASH + stash_n] = (unsigned short)u;
             L.stash_v0[ri * STASH + stash_n] = newv[0];
             L.stash_v1[ri * STASH + stash_n] = newv[1];
@@ -656,13 +604,16 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     }
     if (col >= P->W) col = P->W - 1;
     r.ax = row; r.ay = col;
-    int cls;
-    double p0 = row_prob(c, 0, row, col, 0, true, u32d(w[5]), &cls); r.as = c.L.edges[cls];
-    double p1 = row_prob(c, 1, row, col, 0, true, u32d(w[6]), &cls); r.ar = c.L.edges[MPP_NCLASS + cls];
-    double p2 = row_prob(c, 2, row, col, 0, true, u32d(w[7]), &cls); r.aa = c.L.edges[2 * MPP_NCLASS + cls];
-    // birth density of the drawn point (shape_samplers.py:103-108), same operation order as birth_density()
+    // marks, and on the way the birth density of the drawn point (shape_samplers.py:103-108; same operation
+    // order as birth_density())
     double d = (double)c.t.det[(size_t)row * P->W + col] / tot;
-    d *= p0; d *= p1; d *= p2;
+#pragma clang loop unroll(disable)
+    for (int k = 0; k < 3; ++k) {
+      int cls;
+      d *= row_prob(c, k, row, col, 0, true, u32d(k == 0 ? w[5] : (k == 1 ? w[6] : w[7])), &cls);
+      double val = c.L.edges[k * MPP_NCLASS + cls];
+      if (k == 0) r.as = val; else if (k == 1) r.ar = val; else r.aa = val;
+    }
     r.qf = d * ((double)P->H * (double)P->W * 32768.0);
     *keep = KEEP_QF;
     return;
@@ -675,9 +626,10 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   r.rx = q.x; r.ry = q.y;
   if (k == MPP_K_UDEATH || k == MPP_K_DDEATH) return;
   r.has_add = 1;
+  double z0 = 0.0, z1 = 0.0;
+  if (k == MPP_K_GTRANS || k == MPP_K_GTRANSF)       // words (3,4) for the translation, (4,5) for the mark transform
+    box_muller(k == MPP_K_GTRANS ? w[3] : w[4], k == MPP_K_GTRANS ? w[4] : w[5], &z0, &z1);
   if (k == MPP_K_GTRANS) {
-    double z0, z1;
-    box_muller(w[3], w[4], &z0, &z1);
     double d0 = P->kern.sigma_trans * z0, d1 = P->kern.sigma_trans * z1;
     int nx = (int)((double)q.x + d0), ny = (int)((double)q.y + d1);
     q.x = min(max(nx, 0), P->H - 1); q.y = min(max(ny, 0), P->W - 1);
@@ -691,8 +643,6 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     *keep = KEEP_TRIG | KEEP_SIZE;
   } else if (k == MPP_K_GTRANSF) {
     int pid = (int)mulhi32(w[3], 3u);
-    double z0, z1;
-    box_muller(w[4], w[5], &z0, &z1);
     double d = P->kern.sigma_transform * (P->maps.vmax[pid] - P->maps.vmin[pid]) * z0;
     set_mark(q, pid, wrap_mark(P, pid, mark_of(q, pid) + d));
     r.pid = pid; r.aux0 = d;
@@ -804,13 +754,13 @@ __device__ void write_slot(const Chain &c, int slot, const Rec &q) {
 #ifdef MPP_PROFILE
 #define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
 template <bool LANE>
-__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, int *err,
+__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
                          unsigned long long *prof) {
   unsigned long long pt_ = clock64();
 #else
 #define EPROF(i)
 template <bool LANE>
-__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, int *err) {
+__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply) {
 #endif
   const DevParams *P = c.P;
   const Lds &L = c.L;
@@ -838,10 +788,10 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
     }
     if (LANE)
       r.dE = eval_delta_lane(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
-                             &r.n_stash);
+                             &r.n_stash, apply);
     else
-      r.dE = eval_delta<false>(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
-                               &r.n_stash, err);
+      r.dE = eval_delta(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+                        &r.n_stash, apply);
     EPROF(7);
   }
   double fwd, bwd;

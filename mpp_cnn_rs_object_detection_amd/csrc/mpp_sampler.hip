@@ -58,15 +58,19 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
   }
   __syncthreads();
   err = L.sh[1];
-  {
+  {                                             // cached pair reductions of the initial configuration
     Rect dummy{0, 0, 0, 0, 0};
     Geo2 dg;
     dg.g = Geo{0, 0, 0, 0, 0, 0}; dg.rad = 0.0;
-    for (int u = c.wave; u < n0; u += WAVES)
+    for (int u = tid; u < n0; u += nthr) {
+      Geo2 gu = load_geo(L, u);
+#pragma clang loop unroll(disable)
       for (int p = 0; p < P->model.n_pair; ++p) {
-        double v = rescan_point(c, p, u, -1, false, dummy, dg);
-        if (c.lane == 0) { if (p == 0) L.red0[u] = v; else L.red1[u] = v; }
+        double v = rescan_lane(c, p, u, gu, -1, false, dummy, dg);
+        if (p == 0) L.red0[u] = v; else L.red1[u] = v;
       }
+    }
+    if (tid == 0) L.sh[6] = 0;
   }
   __syncthreads();
 
@@ -84,8 +88,11 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
     PROF_T0();
     // ---- phase A: record ri of this round = step done+ri, evaluated against the current state on the
     //      assumption that the steps before it in this round change nothing it depends on
+    // "apply round": the previous round met an accepted step whose neighbour updates overflow the stash;
+    // it alone is evaluated again (same state, same decision), writing the caches directly
+    const bool apply_round = __builtin_amdgcn_readfirstlane(L.sh[6]) != 0;
     const int ri = LANE ? c.wave * LPW + c.lane : c.wave;
-    const bool mine = LANE ? (c.lane < LPW) : true;
+    const bool mine = (LANE ? (c.lane < LPW) : true) && (!apply_round || ri == 0);
     const long long my = done + ri;
     Rec r;
     r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0;
@@ -125,13 +132,11 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
       PROF_ADD(0);
       if (r.valid && r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
       if (r.valid) {
-        int e2 = 0;
 #ifdef MPP_PROFILE
-        evaluate<LANE>(c, r, ri, keep, n, T, tracing, &e2, prof_);
+        evaluate<LANE>(c, r, ri, keep, n, T, tracing, apply_round, prof_);
 #else
-        evaluate<LANE>(c, r, ri, keep, n, T, tracing, &e2);
+        evaluate<LANE>(c, r, ri, keep, n, T, tracing, apply_round);
 #endif
-        if (e2) { r.valid = 0; r.kernel = -2 - e2; }
       }
 #ifdef MPP_PROFILE
       { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0 && r.kernel >= 0 && r.kernel < 8) { atomicAdd(&g_prof3[r.kernel], n_ - pt_); atomicAdd(&g_prof3[8 + r.kernel], 1ull); } }
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
       PROF_ADD(1);
     }
     if (SPEC > 1) {
-      if (LANE ? mine : (c.lane == 0)) L.rec[ri] = r;
+      if (LANE ? (c.lane < LPW) : (c.lane == 0)) L.rec[ri] = r;    // also the idle ones of an apply round (valid = 0)
       __syncthreads();
     }
     // ---- phase B: wave 0 commits in order
@@ -157,15 +162,13 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
           break;
         }
         if (q.accepted && (q.has_rem || q.has_add)) {
-          if (q.n_stash > STASH) {
-            // more neighbours changed than the stash holds (dense clusters): redo the evaluation in place
-            Rect add{q.ax, q.ay, q.as, q.ar, q.aa};
-            Geo2 ag;
-            ag.g = Geo{q.ax, q.ay, q.hl, q.hw, q.ca, q.sa}; ag.rad = q.rad;
-            double ra0, ra1;
-            int ns, e2 = 0;
-            eval_delta<true>(c, q.has_rem ? q.tslot : -1, q.has_add != 0, add, ag, q.lin_a, q.gate_a, &ra0, &ra1, &ns, &e2);
-          } else if (c.lane < q.n_stash) {
+          if (q.n_stash > STASH && !apply_round) {
+            // more neighbours change than the stash holds (dense clusters): end the round here and redo
+            // this step alone in an apply round
+            if (c.lane == 0) L.sh[6] = 1;
+            break;
+          }
+          if (!apply_round && c.lane < q.n_stash) {
             int u = L.stash_slot[w * STASH + c.lane];
             L.red0[u] = L.stash_v0[w * STASH + c.lane];
             L.red1[u] = L.stash_v1[w * STASH + c.lane];
@@ -241,7 +244,10 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
         committed += 1;
         if (err) break;
       }
-      if (c.lane == 0) { L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; *(double *)(L.sh + 4) = Tc; }
+      if (c.lane == 0) {
+        L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; *(double *)(L.sh + 4) = Tc;
+        if (apply_round) L.sh[6] = 0;
+      }
       PROF_ADD(2);
     }
     __syncthreads();

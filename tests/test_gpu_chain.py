@@ -135,3 +135,48 @@ def test_capacity_overflow_is_reported():
     ctx.set_schedule(1e6, 1.0, 0.0)          # everything is accepted: births pile up
     with pytest.raises(hip_api.MppError):
         ctx.run(5000, 1)
+
+
+@pytest.mark.parametrize("spec,lanes", [(1, 0), (8, 0), (1, 4)])
+def test_more_changed_neighbours_than_the_stash_holds(spec, lanes):
+    """A birth that raises the overlap of 42 neighbours at once (and its death, which makes all of them
+    re-reduce): more updates than one speculative record can stash, so the kernel redoes the step in an
+    'apply round'.  Checked against the oracle by replay."""
+    setup, comb, model = model_for("legacy")
+    t = synth.make_tile(96, 4, tile_id=2, noise=0.1)
+    kd = kernels.make_kernels(mappings.default_mappings(), 1.0)
+    xs, ys = np.meshgrid(np.arange(30, 51, 3), np.arange(28, 46, 3), indexing="ij")
+    xy = np.stack([xs.ravel(), ys.ravel()], axis=1).astype(np.int32)          # 7 x 6 = 42 tiny squares
+    marks = np.tile([[1.0, 1.0, 0.3]], (len(xy), 1))
+    tape = np.zeros(4, hip_api.PROPOSAL_DTYPE)
+    big = dict(ax=40, ay=36, ar=1.0, aa=0.3)
+    tape[0]["kernel"], tape[0]["target"] = 0, -1                              # birth of a 30 x 30 square over all of them
+    tape[1]["kernel"], tape[1]["target"] = 6, 3                               # some unrelated transform
+    tape[1]["param_id"], tape[1]["aux0"] = 0, 0.01
+    tape[2]["kernel"], tape[2]["target"] = 1, len(xy)                         # death of the big square
+    tape[3]["kernel"], tape[3]["target"] = 0, -1                              # and its birth again
+    for i in (0, 3):
+        tape[i]["ax"], tape[i]["ay"], tape[i]["as"], tape[i]["ar"], tape[i]["aa"] = 40, 36, 30.0, 1.0, 0.3
+    tape[1]["ax"], tape[1]["ay"], tape[1]["as"], tape[1]["ar"], tape[1]["aa"] = xy[3, 0], xy[3, 1], 1.01, 1.0, 0.3
+    tape["u_accept"] = 1e-300
+    o = oracle.Oracle(t.shape, t.det, t.marks, model, kd)
+    o.set_points(xy, marks)
+    o.set_temperature(1e12, 1.0, 0.0)
+    ref = o.replay(tape)
+    ctx = hip_api.MppContext(0, point_capacity=128, spec_waves=spec, spec_lanes=lanes)
+    ctx.set_maps(t.det, t.marks)
+    ctx.set_model(model, mappings.default_mappings())
+    ctx.set_kernels(kd)
+    ctx.set_points(0, xy, marks)
+    ctx.set_schedule(1e12, 1.0, 0.0)
+    out = ctx.replay(0, tape)
+    np.testing.assert_array_equal(out["accepted"], [1, 1, 1, 1])
+    np.testing.assert_array_equal(out["n_after"], ref["n_after"])
+    np.testing.assert_allclose(out["dE"], ref["dE"], rtol=1e-9, atol=1e-9)
+    e_gpu, vec = ctx.total_energy(return_vectors=True)
+    ovl = vec[:, ctx.names.index("RectangleOverlapEnergy")]
+    assert (ovl > 0.5).sum() == len(xy) + 1          # every small square (and the big one) now carries an overlap
+    assert e_gpu == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-9)
+    gxy, gm = ctx.get_points()
+    oxy, om = o.get_points()
+    np.testing.assert_array_equal(gxy, oxy)
