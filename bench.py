@@ -138,6 +138,14 @@ def main():
     d = np.sqrt(((final_xy[:, None, :] - tiles[0].gt_xy[None]) ** 2).sum(-1)) if len(final_xy) else np.zeros((0, 1))
     matched = int((d.min(axis=0) <= 2).sum()) if len(final_xy) else 0
 
+    traffic, traffic_src = None, None
+    tj = os.path.join(REPO, "profiles", "latest_traffic.json")
+    if os.path.exists(tj):          # PMC passes cannot run inside this timed process; this is the committed rocprofv3
+        with open(tj) as f:         # measurement of the same command (profiles/run_profile.sh), per launch
+            t = json.load(f)
+        if t.get("iters_per_launch") == args.iters and T == 1:
+            traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
+
     result = {
         "metric": "MPP proposals/s per 512x512 tile",
         "value": value, "unit": "proposals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +161,9 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms,
+            "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "bytes per launch",
+            "algorithmic_bytes_per_launch": bpp * T * args.iters,
+            "kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_proposal": bpp,
             "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
         },

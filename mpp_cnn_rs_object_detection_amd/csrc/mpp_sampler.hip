@@ -3,7 +3,9 @@
 
 // WAVES waves per chain.  LPW == 0: one speculative step per wave, the wave's lanes cooperate on it.
 // LPW > 0 ("lane mode"): lanes 0..LPW-1 of every wave each evaluate their own step.  SPEC steps per round.
-template <int WAVES, int LPW>
+// DIAG = false is the production instantiation: proposals from Philox, nothing recorded (the tape and
+// trace code is compiled out, which also lowers the register need of the hot loop).
+template <int WAVES, int LPW, bool DIAG>
 __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams *P, const TileRef *tiles, int tile0,
                                                                   long long n_steps, unsigned long long seed,
                                                                   unsigned int chain0, const mpp_proposal *tape,
@@ -22,7 +24,8 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // wave-uniform: lets Philox etc. run on the scalar unit
   const Lds &L = c.L;
   const int tid = threadIdx.x, nthr = WAVE * WAVES;
-  const bool tracing = (out != nullptr || props != nullptr) && tile == trace_tile;
+  const bool tracing = DIAG && (out != nullptr || props != nullptr) && tile == trace_tile;
+  if (!DIAG) tape = nullptr;
 
   // ---------------------------------------------------------------- load the configuration
   int n0 = __builtin_amdgcn_readfirstlane(*c.t.n);
@@ -147,6 +150,7 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
       if (LANE ? (c.lane < LPW) : (c.lane == 0)) L.rec[ri] = r;    // also the idle ones of an apply round (valid = 0)
       __syncthreads();
     }
+    PROF_ADD(9);
     // ---- phase B: wave 0 commits in order
     if (c.wave == 0) {
       int committed = 0, cur_n = n;
@@ -294,16 +298,24 @@ extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec
   return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n);
 }
 
+template <int WAVES, int LPW, bool DIAG>
+static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
+                              long long n_steps, unsigned long long seed, unsigned int chain0,
+                              const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG>), dim3(grid), dim3(WAVE * WAVES), lds, st, P, tiles, tile0,
+                     n_steps, seed, chain0, tape, trace_tile, out, props);
+  return hipGetLastError();
+}
 template <int WAVES, int LPW>
 static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                               long long n_steps, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
-  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW>), dim3(grid), dim3(WAVE * WAVES), lds, st, P, tiles, tile0, n_steps,
-                     seed, chain0, tape, trace_tile, out, props);
-  return hipGetLastError();
+  if (tape || out || props)
+    return launch_spec_d<WAVES, LPW, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+  return launch_spec_d<WAVES, LPW, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
 }
 
 // spec = steps evaluated per round; lanes = 0: one wave per step (spec waves); lanes > 0: 4 waves x lanes lanes

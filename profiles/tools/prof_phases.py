@@ -15,7 +15,7 @@ for spec in (1, 8):
     ctx.set_schedule(1.0, 0.999, 0.0)
     ctx.run(100001, seed=0)
     buf = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof(buf)
-    v = np.array(list(buf), dtype=float); names = ['draw','evaluate','commit','sync','dens','geom','unit','evalD','green']
+    v = np.array(list(buf), dtype=float); names = ['draw','evaluate','commit','sync','dens','geom','unit','evalD','green','barrier_wait']
     buf2 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof2(buf2, 1)
     print('   evalD parts (setup, cand, slow, stash, combine):', [round(x/100001) for x in list(buf2)[:5]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001)
     buf3 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof3(buf3)
