@@ -112,15 +112,11 @@ extern "C" void mpp_launch_naive_init(hipStream_t st, const DevParams *P, const 
 }
 
 // ---- PosNet epilogue --------------------------------------------------------------------------------
-// out: [3][Hp][ldw] float32 (vec0 = d/d row component, vec1 = d/d col component, mask logit);
+// out: [3][ldh][ldw] float32 (vec0 = d/d row component, vec1 = d/d col component, mask logit);
 // det[x][y] = sigmoid(w * (d vec0/dx + d vec1/dy) * sigmoid(mask) + b), central differences inside,
 // one-sided at the borders of the H x W region (torch.gradient semantics).
-__global__ __launch_bounds__(256) void k_posnet_epilogue(const float *out, int H, int W, int ldh, int ldw, float w,
-                                                         float b, float *det) {
-  int y = blockIdx.x * blockDim.x + threadIdx.x, x = blockIdx.y;
-  if (y >= W || x >= H) return;
-  const size_t plane = (size_t)ldh * ldw;
-  const float *v0 = out, *v1 = out + plane, *mk = out + 2 * plane;
+__device__ __forceinline__ float posnet_pixel(const float *v0, const float *v1, const float *mk, int x, int y, int H,
+                                              int W, int ldw, float w, float b) {
   float g0, g1;
   if (H == 1) g0 = 0.f;
   else if (x == 0) g0 = v0[(size_t)1 * ldw + y] - v0[y];
@@ -132,24 +128,66 @@ __global__ __launch_bounds__(256) void k_posnet_epilogue(const float *out, int H
   else g1 = (v1[(size_t)x * ldw + y + 1] - v1[(size_t)x * ldw + y - 1]) / 2.0f;
   float mask = 1.0f / (1.0f + expf(-mk[(size_t)x * ldw + y]));
   float score = w * ((g0 + g1) * mask) + b;
-  det[(size_t)x * W + y] = 1.0f / (1.0f + expf(-score));
+  return 1.0f / (1.0f + expf(-score));
+}
+// each thread produces 4 consecutive pixels of a row: 16-byte loads of the rows above/below, of the row
+// itself (plus its two neighbours) and of the mask, one 16-byte store
+__global__ __launch_bounds__(256) void k_posnet_epilogue(const float *out, int H, int W, int ldh, int ldw, float w,
+                                                         float b, float *det, int vec_ok) {
+  const int y4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4, x = blockIdx.y;
+  if (y4 >= W || x >= H) return;
+  const size_t plane = (size_t)ldh * ldw;
+  const float *v0 = out, *v1 = out + plane, *mk = out + 2 * plane;
+  if (vec_ok && x > 0 && x < H - 1 && y4 > 0 && y4 + 4 < W) {
+    const float4 up = *(const float4 *)(v0 + (size_t)(x - 1) * ldw + y4), dn = *(const float4 *)(v0 + (size_t)(x + 1) * ldw + y4);
+    const float4 c = *(const float4 *)(v1 + (size_t)x * ldw + y4), m4 = *(const float4 *)(mk + (size_t)x * ldw + y4);
+    const float left = v1[(size_t)x * ldw + y4 - 1], right = v1[(size_t)x * ldw + y4 + 4];
+    const float g0[4] = {(dn.x - up.x) / 2.0f, (dn.y - up.y) / 2.0f, (dn.z - up.z) / 2.0f, (dn.w - up.w) / 2.0f};
+    const float g1[4] = {(c.y - left) / 2.0f, (c.z - c.x) / 2.0f, (c.w - c.y) / 2.0f, (right - c.z) / 2.0f};
+    const float mm[4] = {m4.x, m4.y, m4.z, m4.w};
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float mask = 1.0f / (1.0f + expf(-mm[i]));
+      float score = w * ((g0[i] + g1[i]) * mask) + b;
+      r[i] = 1.0f / (1.0f + expf(-score));
+    }
+    *(float4 *)(det + (size_t)x * W + y4) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+    for (int y = y4; y < min(y4 + 4, W); ++y) det[(size_t)x * W + y] = posnet_pixel(v0, v1, mk, x, y, H, W, ldw, w, b);
+  }
 }
 extern "C" void mpp_launch_posnet_epilogue(hipStream_t st, const float *out, int H, int W, int ldh, int ldw, float w,
                                            float b, float *det) {
-  hipLaunchKernelGGL(k_posnet_epilogue, dim3((W + 255) / 256, H), dim3(256), 0, st, out, H, W, ldh, ldw, w, b, det);
+  int vec_ok = (ldw % 4 == 0) && (W % 4 == 0) && (((uintptr_t)out & 15) == 0) && (((uintptr_t)det & 15) == 0) &&
+               (((size_t)ldh * ldw) % 4 == 0);
+  hipLaunchKernelGGL(k_posnet_epilogue, dim3((W + 1023) / 1024, H), dim3(256), 0, st, out, H, W, ldh, ldw, w, b, det,
+                     vec_ok);
 }
 
 // ---- ShapeNet epilogue --------------------------------------------------------------------------------
-// logits: [32][ldh][ldw] -> marks [H][W][32] = softmax over classes.  One block = 64 pixels of a row.
+// logits: [32][ldh][ldw] -> marks [H][W][32] = softmax over classes.  One block = 64 pixels of a row:
+// 16-byte loads (4 pixels of one channel per lane), transpose through LDS, 2 x 16-byte stores per lane
+// (one pixel's 32 classes = 128 contiguous bytes from 4 lanes).
 __global__ __launch_bounds__(256) void k_shapenet_epilogue(const float *logits, int H, int W, int ldh, int ldw,
-                                                           float *marks) {
+                                                           float *marks, int vec_ok) {
   __shared__ float tile[MPP_NCLASS][WAVE + 1];
   const int x = blockIdx.y, y0 = blockIdx.x * WAVE;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;      // 4 waves, each reads 8 channels
   const size_t plane = (size_t)ldh * ldw;
-  for (int ch = grp; ch < MPP_NCLASS; ch += 4) {
-    int y = y0 + lane;
-    tile[ch][lane] = y < W ? logits[ch * plane + (size_t)x * ldw + y] : 0.f;
+  if (vec_ok && y0 + WAVE <= W) {
+    const int px4 = (threadIdx.x & 15) * 4, ch0 = threadIdx.x >> 4;      // 16 lanes cover the 64 pixels of a channel
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ch = ch0 + 16 * h;
+      const float4 v = *(const float4 *)(logits + ch * plane + (size_t)x * ldw + y0 + px4);
+      tile[ch][px4] = v.x; tile[ch][px4 + 1] = v.y; tile[ch][px4 + 2] = v.z; tile[ch][px4 + 3] = v.w;
+    }
+  } else {
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int ch = grp; ch < MPP_NCLASS; ch += 4) {
+      int y = y0 + lane;
+      tile[ch][lane] = y < W ? logits[ch * plane + (size_t)x * ldw + y] : 0.f;
+    }
   }
   __syncthreads();
   // pixel p = threadIdx.x / 4 handles 8 classes: threads of one pixel sit in one wave -> shuffles
@@ -170,6 +208,7 @@ __global__ __launch_bounds__(256) void k_shapenet_epilogue(const float *logits, 
 }
 extern "C" void mpp_launch_shapenet_epilogue(hipStream_t st, const float *logits, int H, int W, int ldh, int ldw,
                                              float *marks) {
+  int vec_ok = (ldw % 4 == 0) && (((uintptr_t)logits & 15) == 0) && (((size_t)ldh * ldw) % 4 == 0);
   hipLaunchKernelGGL(k_shapenet_epilogue, dim3((W + WAVE - 1) / WAVE, H), dim3(256), 0, st, logits, H, W, ldh, ldw,
-                     marks);
+                     marks, vec_ok);
 }
