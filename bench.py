@@ -67,14 +67,17 @@ def main():
     from mpp_cnn_rs_object_detection_amd import distributed as mdist
     from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings, synth
 
-    rank, world = mdist.init_process_group()
+    # RCCL ("nccl") by default; MPP_DIST_BACKEND=gloo lets several ranks share one GPU for a functional rehearsal
+    rank, world = mdist.init_process_group(backend=os.environ.get("MPP_DIST_BACKEND"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the sampler has no CPU fallback")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    gather_device = device if torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl" else None
 
     setup, model = load_model()
     maps = mappings.default_mappings()
@@ -99,7 +102,7 @@ def main():
         if world > 1:
             pts = [ctx.get_points(i) for i in range(T)]
             buf = mdist.pack_detections([rank * T + i for i in range(T)], pts, [None] * T, capacity=1024 * T)
-            mdist.all_gather_detections(buf, device=device)
+            mdist.all_gather_detections(buf, device=gather_device)
         return ctx.last_kernel_ms()
 
     def barrier():
@@ -125,7 +128,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=gather_device or "cpu")
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -220,7 +220,7 @@ __device__ unsigned long long g_prof2[16];
 #endif
 // `apply`: write the changed reductions straight into the caches instead of the stash (used for the rare
 // step whose neighbour updates do not fit the stash; see the kernel's "apply round").
-__device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
+__device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
                              int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
@@ -316,9 +316,9 @@ __device__ double eval_delta(const Chain &c, int rem, bool has_add, const Rect &
     if (!apply && changed) {
       int rank = stash_n + __popcll(cm & ((1ull << c.lane) - 1ull));
       if (rank < STASH) {
-        L.stash_slot[c.wave * STASH + rank] = (unsigned short)u;
-        L.stash_v0[c.wave * STASH + rank] = newv[0];
-        L.stash_v1[c.wave * STASH + rank] = newv[1];
+        L.stash_slot[ri * STASH + rank] = (unsigned short)u;
+        L.stash_v0[ri * STASH + rank] = newv[0];
+        L.stash_v1[ri * STASH + rank] = newv[1];
       }
     }
     stash_n += __popcll(cm);
@@ -790,7 +790,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
       r.dE = eval_delta_lane(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
                              &r.n_stash, apply);
     else
-      r.dE = eval_delta(c, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+      r.dE = eval_delta(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
                         &r.n_stash, apply);
     EPROF(7);
   }

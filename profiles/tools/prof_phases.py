@@ -8,8 +8,8 @@ import bench
 from mpp_cnn_rs_object_detection_amd import kernels, mappings, synth
 setup, model = bench.load_model(); maps = mappings.default_mappings()
 t = synth.make_tile(512, 200, 0)
-for spec in (1, 8):
-    ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=spec)
+for spec, lanes in ((1, 0), (8, 0), (1, 1), (1, 4)):
+    ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=spec, spec_lanes=lanes)
     ctx.set_maps(t.det, t.marks); ctx.set_model(model, maps); ctx.naive_init(setup.detection_threshold, 6.0)
     xy, mk = ctx.get_points(); ctx.set_kernels(kernels.make_kernels(maps, float(len(xy))))
     ctx.set_schedule(1.0, 0.999, 0.0)
@@ -20,4 +20,4 @@ for spec in (1, 8):
     print('   evalD parts (setup, cand, slow, stash, combine):', [round(x/100001) for x in list(buf2)[:5]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001)
     buf3 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof3(buf3)
     print('   evaluate cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf3[k]/max(1,buf3[8+k])) for k in range(8)], 'counts', list(buf3)[8:16])
-    print('spec', spec, 'kernel ms', ctx.last_kernel_ms(), {n: round(x/100001) for n, x in zip(names, v)}, 'sum', round(v.sum()/100001), 'clock64 ticks/step')
+    print('spec', spec, 'lanes', lanes, 'kernel ms', ctx.last_kernel_ms(), {n: round(x/100001) for n, x in zip(names, v)}, 'sum', round(v.sum()/100001), 'clock64 ticks/step')
