@@ -60,7 +60,10 @@ def main():
     ap.add_argument("--batched-tiles", type=int, default=0,
                     help="extra, untimed-in-`value` measurement: this many 256x256 tiles (the reference's tile size, "
                          "50 objects, mpp_hrcM schedule of 30257 steps) sampled concurrently, one workgroup per tile")
-    ap.add_argument("--batched-spec", type=int, default=2)
+    ap.add_argument("--batched-spec", type=int, default=1)
+    ap.add_argument("--batched-tile", type=int, default=256)
+    ap.add_argument("--batched-objects", type=int, default=50)
+    ap.add_argument("--batched-capacity", type=int, default=128, help="point slots per chain in the batched run")
     args = ap.parse_args()
 
     import torch
@@ -173,14 +176,12 @@ def main():
     }
 
     if rank == 0 and world == 1 and args.batched_tiles > 0:
-        B, bt, bobj, biters = args.batched_tiles, 256, 50, 30257
+        B, bt, bobj, biters = args.batched_tiles, args.batched_tile, args.batched_objects, 30257
         base = [synth.make_tile(bt, bobj, tile_id=1000 + i) for i in range(min(B, 8))]
         reps = (B + len(base) - 1) // len(base)
-        bdet = np.concatenate([np.stack([t.det for t in base])] * reps)[:B]
-        bmarks = [np.concatenate([np.stack([t.marks[k] for t in base])] * reps)[:B] for k in range(3)]
-        bctx = hip_api.MppContext(local, point_capacity=256, spec_waves=args.batched_spec)
-        bctx.set_maps(bdet, bmarks)
-        del bdet, bmarks
+        B = reps * len(base)                       # 8 distinct tiles, `reps` chains (own chain id) on each of them
+        bctx = hip_api.MppContext(local, point_capacity=args.batched_capacity, spec_waves=args.batched_spec, replicas=reps)
+        bctx.set_maps(np.stack([t.det for t in base]), [np.stack([t.marks[k] for t in base]) for k in range(3)])
         bctx.set_model(model, maps)
         bctx.naive_init(setup.detection_threshold, 6.0)
         binten = np.array([max(1, bctx.count(i)) for i in range(B)], dtype=np.float64)
@@ -197,7 +198,7 @@ def main():
         brate = B * biters / (kms * 1e-3)
         bbpp = bytes_per_proposal(float(n_end.mean()), (bt // 32) ** 2, acc)
         result["batched"] = {
-            "tiles": B, "tile": bt, "objects": bobj, "iters": biters, "spec_waves": args.batched_spec,
+            "tiles": B, "distinct_tiles": len(base), "point_capacity": args.batched_capacity, "tile": bt, "objects": bobj, "iters": biters, "spec_waves": args.batched_spec,
             "proposals_per_s": brate, "kernel_ms": kms, "wall_s": wall, "mean_final_points": float(n_end.mean()),
             "roofline": {"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS},

@@ -117,7 +117,8 @@ int mpp_synchronize(mpp_ctx *ctx);
 /* "spec_waves": proposals evaluated speculatively per round, one wave each (1 = strictly one at a
  * time); "spec_lanes" (0 = off): lane mode, 4 waves of which `v` lanes each evaluate one step on
  * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile, "cell_capacity" (points per
- * 32-px cell), "force_accept": apply every proposal without the Metropolis test (the kernel random
+ * 32-px cell), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
+ * tile t % n_tiles; "force_accept": apply every proposal without the Metropolis test (the kernel random
  * walks of models/mpp/perturbation_sampler.py:152-169) */
 int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);
 int64_t mpp_get_option(mpp_ctx *ctx, const char *name);

@@ -9,11 +9,11 @@
 
 #include "mpp_device.hpp"
 
-extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n);
-extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int grid, size_t lds, const DevParams *P,
-                                       const TileRef *tiles, int tile0, long long n_steps, unsigned long long seed,
-                                       unsigned int chain0, const mpp_proposal *tape, int trace_tile,
-                                       mpp_step_out *out, mpp_proposal *props);
+extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves);
+extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int occ, int grid, size_t lds,
+                                       const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
+                                       unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
+                                       int trace_tile, mpp_step_out *out, mpp_proposal *props);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors);
 extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -46,6 +46,7 @@ struct mpp_ctx {
   double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
   bool box_dirty = true;
   int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
+  int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
   int64_t *step = nullptr;
@@ -163,6 +164,12 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     // lane mode: 4 waves, `v` lanes of each evaluate one speculative step each (4*v steps per round); 0 = off
     if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_lanes must be 0, 1, 2, 4, 8 or 16");
     c->lanes = (int)v;
+  } else if (!strcmp(name, "replicas")) {
+    // independent replica chains per tile: mpp_set_maps(n_tiles = M) then creates M*v chains, chain t on the maps
+    // of tile t % M (several chains of one tile with different chain ids, or a benchmark's many-tile load)
+    if (c->have_maps) return fail(c, -1, "replicas must be set before mpp_set_maps");
+    if (v < 1 || v > 65536) return fail(c, -1, "replicas out of range");
+    c->replicas = (int)v;
   } else if (!strcmp(name, "point_capacity")) {
     if (c->have_maps) return fail(c, -1, "point_capacity must be set before mpp_set_maps");
     if (v < 1 || v > 65535) return fail(c, -1, "point_capacity out of range");
@@ -180,13 +187,15 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "spec_waves")) return c->spec;
   if (!strcmp(name, "spec_lanes")) return c->lanes;
   if (!strcmp(name, "point_capacity")) return c->cap;
+  if (!strcmp(name, "replicas")) return c->replicas;
+  if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
   if (!strcmp(name, "lds_bytes")) {
     int ncell = c->hp.nx * c->hp.ny;
     int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
     int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
-    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb);
+    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
   }
   return -1;
 }
@@ -274,13 +283,13 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   free_tiles(c);
-  c->n_tiles = n_tiles; c->H = H; c->W = W;
-  const size_t hw = (size_t)H * W, T = (size_t)n_tiles;
+  c->n_maps = n_tiles; c->n_tiles = n_tiles * c->replicas; c->H = H; c->W = W;
+  const size_t hw = (size_t)H * W, M = (size_t)n_tiles, T = (size_t)c->n_tiles;
   const float *src[4] = {det, m0, m1, m2};
   float **dst[4] = {&c->det, &c->m[0], &c->m[1], &c->m[2]};
   c->maps_borrowed = on_device != 0;
   for (int k = 0; k < 4; ++k) {
-    size_t cnt = T * hw * (k == 0 ? 1 : MPP_NCLASS);
+    size_t cnt = M * hw * (k == 0 ? 1 : MPP_NCLASS);
     if (on_device) {
       if (!src[k]) return fail(c, -1, "borrowed device maps must all be given");
       *dst[k] = const_cast<float *>(src[k]);
@@ -290,10 +299,10 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
       else HIPCHK(c, hipMemsetAsync(*dst[k], 0, cnt * sizeof(float), c->stream));
     }
   }
-  HIPCHK(c, dalloc(&c->rowpart, T * hw));
-  HIPCHK(c, dalloc(&c->rowbase, T * (H + 1)));
-  HIPCHK(c, dalloc(&c->rowtot, T * H));
-  HIPCHK(c, dalloc(&c->boxsum, T * hw));
+  HIPCHK(c, dalloc(&c->rowpart, M * hw));
+  HIPCHK(c, dalloc(&c->rowbase, M * (H + 1)));
+  HIPCHK(c, dalloc(&c->rowtot, M * H));
+  HIPCHK(c, dalloc(&c->boxsum, M * hw));
   c->box_dirty = true;
   HIPCHK(c, dalloc(&c->px, T * c->cap)); HIPCHK(c, dalloc(&c->py, T * c->cap));
   HIPCHK(c, dalloc(&c->ps, T * c->cap)); HIPCHK(c, dalloc(&c->pr, T * c->cap)); HIPCHK(c, dalloc(&c->pa, T * c->cap));
@@ -305,11 +314,11 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   std::vector<double> sched(T * 3);
   for (size_t t = 0; t < T; ++t) { sched[3 * t] = c->sched[0]; sched[3 * t + 1] = c->sched[1]; sched[3 * t + 2] = c->sched[2]; }
   HIPCHK(c, hipMemcpyAsync(c->T, sched.data(), sched.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  for (size_t t = 0; t < T; ++t)
+  for (size_t t = 0; t < M; ++t)
     mpp_launch_cdf(c->stream, c->det + t * hw, H, W, c->rowpart + t * hw, c->rowbase + t * (H + 1), c->rowtot + t * H);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if ((int)c->intensity.size() != n_tiles) c->intensity.assign(n_tiles, 1.0);
+  if ((int)c->intensity.size() != c->n_tiles) c->intensity.assign(c->n_tiles, 1.0);
   c->have_maps = true;
   c->tiles_dirty = true;
   refresh_grid(c);
@@ -325,10 +334,11 @@ static int push_state(mpp_ctx *c) {
     c->h_tiles.resize(c->n_tiles);
     for (int t = 0; t < c->n_tiles; ++t) {
       TileRef &r = c->h_tiles[t];
-      r.det = c->det + t * hw;
-      for (int k = 0; k < 3; ++k) r.m[k] = c->m[k] + t * hw * MPP_NCLASS;
-      r.rowpart = c->rowpart + t * hw; r.rowbase = c->rowbase + (size_t)t * (c->H + 1);
-      r.boxsum = c->boxsum + t * hw;
+      const size_t m = (size_t)(t % c->n_maps);                    // replica chains share their tile's maps
+      r.det = c->det + m * hw;
+      for (int k = 0; k < 3; ++k) r.m[k] = c->m[k] + m * hw * MPP_NCLASS;
+      r.rowpart = c->rowpart + m * hw; r.rowbase = c->rowbase + m * (c->H + 1);
+      r.boxsum = c->boxsum + m * hw;
       r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
@@ -341,7 +351,7 @@ static int push_state(mpp_ctx *c) {
   }
   if (c->box_dirty && c->have_kernels) {
     const size_t hw = (size_t)c->H * c->W;
-    for (int t = 0; t < c->n_tiles; ++t)
+    for (int t = 0; t < c->n_maps; ++t)
       mpp_launch_boxsum(c->stream, c->rowpart + t * hw, c->H, c->W, c->hp.kern.max_delta, c->boxsum + t * hw);
     HIPCHK(c, hipGetLastError());
     c->box_dirty = false;
@@ -541,12 +551,14 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   const int ncell = c->hp.nx * c->hp.ny;
   const int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
   const int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
-  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, spec, rb);
+  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
   if (lds > MPP_LDS_LIMIT)
     return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
                 lds, MPP_LDS_LIMIT);
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
+  // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
+  const int occ = (grid >= 1024) ? 2 : 1;
+  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
                              d_tape, trace_tile, d_out, d_props));
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev1));

@@ -56,6 +56,7 @@ struct Lds {
   double *edges;              // [3][32] copy of the mark bin edges
   double *rowbase;            // [H+1] copy of the birth CDF's row level (lane mode, H <= 1024), else nullptr
   double *stash_v0, *stash_v1;
+  double *clip;               // [waves][CLIP_SLOTS][32] polygon buffers of the rectangle clipper
   int *xy;
   unsigned short *order, *cell_items, *cell_cnt, *stash_slot;
   unsigned char *gate;
@@ -64,8 +65,10 @@ struct Lds {
 };
 
 #define ROWBASE_LDS_MAX 1024
-__host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n) {
+#define CLIP_SLOTS 4          // lanes of one wave that clip at the same time (the others take the next turn)
+__host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves) {
   size_t b = 0;
+  b += (size_t)waves * CLIP_SLOTS * 32 * sizeof(double);
   b += (size_t)11 * cap * sizeof(double);
   b += (size_t)rowbase_n * sizeof(double);
   b += (size_t)3 * MPP_NCLASS * sizeof(double);
@@ -82,7 +85,7 @@ __host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, in
   return b + 64;
 }
 
-__device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_cap, int spec, int rowbase_n) {
+__device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves) {
   Lds L;
   double *d = (double *)base;
   L.s = d; d += cap; L.r = d; d += cap; L.a = d; d += cap; L.ca = d; d += cap; L.sa = d; d += cap;
@@ -91,6 +94,7 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
   L.edges = d; d += 3 * MPP_NCLASS;
   L.rowbase = rowbase_n > 0 ? d : nullptr; d += rowbase_n;
   L.stash_v0 = d; d += (size_t)spec * STASH; L.stash_v1 = d; d += (size_t)spec * STASH;
+  L.clip = d; d += (size_t)waves * CLIP_SLOTS * 32;
   L.xy = (int *)d;
   unsigned short *u = (unsigned short *)(L.xy + cap);
   L.order = u; u += cap;
@@ -157,11 +161,79 @@ __device__ __forceinline__ bool slot_first(const Lds &L, int u, const Geo &gu, i
   if (gu.y != vy) return gu.y < vy;
   return rect_less(gu.x, gu.y, L.s[u], L.r[u], L.a[u], vx, vy, vs, vr, va);
 }
+// Sutherland-Hodgman with the two 8-vertex polygon buffers in LDS instead of private (scratch) arrays: same
+// arithmetic, same order as clip_area() of mpp_device.hpp (which the from-scratch kernels use), so the values
+// agree bit for bit.  buf: 32 doubles = ax[8] ay[8] bx[8] by[8].
+__device__ inline double clip_area_lds(double *buf, const double *sx, const double *sy, const double *cx,
+                                       const double *cy) {
+  double *ax = buf, *ay = buf + 8, *bx = buf + 16, *by = buf + 24;
+  int na = 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ax[i] = sx[i]; ay[i] = sy[i]; }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {           // unrolled: the clipper's corners stay in registers (static indices)
+    if (na <= 0) break;
+    double x0 = cx[e], y0 = cy[e], x1 = cx[(e + 1) & 3], y1 = cy[(e + 1) & 3];
+    double ex = x1 - x0, ey = y1 - y0;
+    int nb = 0;
+    double px = ax[na - 1], py = ay[na - 1];
+    double sp = ex * (py - y0) - ey * (px - x0);
+    for (int i = 0; i < na; ++i) {
+      double qx = ax[i], qy = ay[i];
+      double sq = ex * (qy - y0) - ey * (qx - x0);
+      if (sq >= 0) {
+        if (sp < 0 && nb < 8) {
+          double t = sp / (sp - sq);
+          bx[nb] = px + t * (qx - px); by[nb] = py + t * (qy - py); ++nb;
+        }
+        if (nb < 8) { bx[nb] = qx; by[nb] = qy; ++nb; }
+      } else if (sp >= 0 && nb < 8) {
+        double t = sp / (sp - sq);
+        bx[nb] = px + t * (qx - px); by[nb] = py + t * (qy - py); ++nb;
+      }
+      px = qx; py = qy; sp = sq;
+    }
+    double *tx = ax, *ty = ay;           // swap the roles of the two buffers (clip_area copies b back into a)
+    ax = bx; ay = by; bx = tx; by = ty;
+    na = nb;
+  }
+  if (na < 3) return 0.0;
+  double s = 0.0;
+  for (int i = 0; i < na; ++i) {
+    int j = (i + 1 == na) ? 0 : i + 1;
+    s += ax[i] * ay[j] - ax[j] * ay[i];
+  }
+  return 0.5 * fabs(s);
+}
+// RectangleOverlapEnergy for the chain: lanes that really have to clip (circumscribed circles meet) take turns
+// on the wave's CLIP_SLOTS polygon buffers.  Works in divergent code too: the ballots only see active lanes.
+__device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, const Geo &v, bool u_first, double ru,
+                                              double rv, double d2) {
+  double A = geo_area(u), B = geo_area(v);
+  double mn = A < B ? A : B;
+  double reach = ru + rv;
+  bool need = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
+  double area = 0.0;
+  unsigned long long m = __ballot(need);
+  while (m) {
+    int rank = __popcll(m & ((1ull << c.lane) - 1ull));
+    if (need && rank < CLIP_SLOTS) {
+      double ax[4], ay[4], bx[4], by[4];
+      if (u_first) { geo_corners(u, ax, ay); geo_corners(v, bx, by); }
+      else { geo_corners(v, ax, ay); geo_corners(u, bx, by); }
+      area = clip_area_lds(c.L.clip + ((size_t)c.wave * CLIP_SLOTS + rank) * 32, ax, ay, bx, by) / (mn + AREA_EPS);
+      need = false;
+    }
+    m = __ballot(need);
+  }
+  return area;
+}
+
 // pair energy of (u, v); d2 = squared centre distance (integer valued)
-__device__ __forceinline__ double pair_value(const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v, bool u_first,
-                                             int d2) {
+__device__ __forceinline__ double pair_value(const Chain &c, const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v,
+                                             bool u_first, int d2) {
   switch (pt.kind) {
-    case MPP_P_OVERLAP: return overlap_energy_r(u.g, v.g, u_first, u.rad, v.rad, (double)d2);
+    case MPP_P_OVERLAP: return overlap_energy_chain(c, u.g, v.g, u_first, u.rad, v.rad, (double)d2);
     case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
     case MPP_P_DIST_LE: return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0;
     case MPP_P_DIST_LT: return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0;
@@ -193,7 +265,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
         if (d2 <= P->maxd2[p]) {
           Geo2 gw = load_geo(L, w);
           bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
-          acc = reduce2(pt.reduce, acc, pair_value(pt, gu, gw, uf, d2));
+          acc = reduce2(pt.reduce, acc, pair_value(c, pt, gu, gw, uf, d2));
         }
       }
     }
@@ -201,7 +273,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
     int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
     if (d2 <= P->maxd2[p]) {
       bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
-      acc = reduce2(pt.reduce, acc, pair_value(pt, gu, ag, uf, d2));
+      acc = reduce2(pt.reduce, acc, pair_value(c, pt, gu, ag, uf, d2));
     }
   }
   return acc;
@@ -289,7 +361,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
           const Geo2 gv = which == 0 ? gr : ag;
           const Rect rv = which == 0 ? rr : ar;
           const bool uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
-          const double v = pair_value(pt, gu, gv, uf, which == 0 ? d2r : d2a);
+          const double v = pair_value(c, pt, gu, gv, uf, which == 0 ? d2r : d2a);
           if (which == 0) slow = (v == ov);
           else {
             double &rap = p == 0 ? ra[0] : ra[1];
@@ -479,11 +551,11 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
           bool slow = false;
           if (in_r && oldv[p] != 0.0) {
             bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
-            if (pair_value(pt, gu, gr, uf, d2r) == oldv[p]) slow = true;     // the removed point carries u's extremum
+            if (pair_value(c, pt, gu, gr, uf, d2r) == oldv[p]) slow = true;     // the removed point carries u's extremum
           }
           if (in_a) {
             bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
-            double v_a = pair_value(pt, gu, ag, uf, d2a);
+            double v_a = pair_value(c, pt, gu, ag, uf, d2a);
             ra[p] = reduce2(pt.reduce, ra[p], v_a);
             nv = reduce2(pt.reduce, nv, v_a);
           }

@@ -92,6 +92,9 @@ __device__ __forceinline__ void geo_corners(const Geo &g, double *px, double *py
 
 // Sutherland-Hodgman: area of (convex quad S) clipped by (convex ccw quad C)
 __device__ inline double clip_area(const double *sx, const double *sy, const double *cx, const double *cy) {
+#ifdef MPP_NOCLIP                     // timing experiment only (wrong areas): no private arrays -> no scratch
+  return 0.5 * (sx[0] * cy[1] - cx[0] * sy[1]);
+#endif
   double ax[8], ay[8], bx[8], by[8];
   int na = 4;
 #pragma unroll
@@ -244,15 +247,19 @@ __device__ inline double unit_value(const DevParams *P, const TileRef &t, const 
 __device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
                                  const Geo &g, double *lin, int *gate, double *vec_or_null) {
   const mpp_model &M = P->model;
-  double v[MPP_MAX_UNIT];
-  for (int k = 0; k < M.n_unit; ++k) {
-    v[k] = unit_value(P, t, edges, M.unit[k], q, g);
-    if (vec_or_null) vec_or_null[k] = v[k];
-  }
+  // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
+  double vg = 0.0;
   int gt = 1;
-  if (M.gate_term >= 0) gt = (v[M.gate_term] <= M.gate_thr) ? 1 : 0;
+  if (M.gate_term >= 0) {
+    vg = unit_value(P, t, edges, M.unit[M.gate_term], q, g);
+    gt = (vg <= M.gate_thr) ? 1 : 0;
+  }
   double l = M.lin0;
-  for (int k = 0; k < M.n_unit; ++k) l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v[k];
+  for (int k = 0; k < M.n_unit; ++k) {
+    double v = (k == M.gate_term) ? vg : unit_value(P, t, edges, M.unit[k], q, g);
+    if (vec_or_null) vec_or_null[k] = v;
+    l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
+  }
   *lin = l; *gate = gt;
 }
 __device__ __forceinline__ double pair_part(const DevParams *P, int gate, double r0, double r1) {

@@ -5,8 +5,11 @@
 // LPW > 0 ("lane mode"): lanes 0..LPW-1 of every wave each evaluate their own step.  SPEC steps per round.
 // DIAG = false is the production instantiation: proposals from Philox, nothing recorded (the tape and
 // trace code is compiled out, which also lowers the register need of the hot loop).
-template <int WAVES, int LPW, bool DIAG>
-__global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams *P, const TileRef *tiles, int tile0,
+// OCC: minimum waves per SIMD the register allocation must allow.  The hot loop wants ~340 VGPRs, i.e. ONE
+// wave per SIMD; throughput runs over many tiles ask for OCC = 2 (256 VGPRs, a few spills) so that two chains
+// share a SIMD and hide each other's latencies.
+template <int WAVES, int LPW, bool DIAG, int OCC>
+__global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams *P, const TileRef *tiles, int tile0,
                                                                   long long n_steps, unsigned long long seed,
                                                                   unsigned int chain0, const mpp_proposal *tape,
                                                                   int trace_tile, mpp_step_out *out,
@@ -19,7 +22,7 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
   c.P = P; c.t = tiles[tile];
   const int ncell = P->nx * P->ny, cap = P->cap;
   const int rowbase_n = (LANE && P->H <= ROWBASE_LDS_MAX) ? P->H + 1 : 0;
-  c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC, rowbase_n);
+  c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC, rowbase_n, WAVES);
   c.lane = threadIdx.x & (WAVE - 1);
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // wave-uniform: lets Philox etc. run on the scalar unit
   const Lds &L = c.L;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(WAVE *WAVES) void mpp_chain_kernel(const DevParams 
       } else {
         uint32_t w[12];
         uint64_t s = (uint64_t)(step0 + my);
+#pragma unroll
         for (uint32_t b = 0; b < 3; ++b)
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
         draw_proposal<LANE>(c, w, n, r, &keep);
@@ -294,36 +298,40 @@ extern "C" void mpp_debug_read_prof2(unsigned long long *out, int reset) {
 #endif
 
 // ---- host-side launcher ----------------------------------------------------------------------------
-extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n) {
-  return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n);
+extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves) {
+  return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n, waves);
 }
 
-template <int WAVES, int LPW, bool DIAG>
+template <int WAVES, int LPW, bool DIAG, int OCC>
 static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                               long long n_steps, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
-  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG>,
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG>), dim3(grid), dim3(WAVE * WAVES), lds, st, P, tiles, tile0,
+  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC>), dim3(grid), dim3(WAVE * WAVES), lds, st, P, tiles, tile0,
                      n_steps, seed, chain0, tape, trace_tile, out, props);
   return hipGetLastError();
 }
 template <int WAVES, int LPW>
 static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                               long long n_steps, unsigned long long seed, unsigned int chain0,
-                              const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
+                              const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props,
+                              int occ) {
+  constexpr int BASE = (WAVES + 3) / 4;      // waves per SIMD one workgroup needs anyway
   if (tape || out || props)
-    return launch_spec_d<WAVES, LPW, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
-  return launch_spec_d<WAVES, LPW, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+    return launch_spec_d<WAVES, LPW, true, BASE>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+  if (WAVES <= 4 && LPW == 0 && occ >= 2)
+    return launch_spec_d<WAVES, LPW, false, 2>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+  return launch_spec_d<WAVES, LPW, false, BASE>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
 }
 
 // spec = steps evaluated per round; lanes = 0: one wave per step (spec waves); lanes > 0: 4 waves x lanes lanes
-extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int grid, size_t lds, const DevParams *P,
-                                       const TileRef *tiles, int tile0, long long n_steps, unsigned long long seed,
-                                       unsigned int chain0, const mpp_proposal *tape, int trace_tile,
-                                       mpp_step_out *out, mpp_proposal *props) {
-#define GO(W, L) return launch_spec<W, L>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props)
+extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int occ, int grid, size_t lds,
+                                       const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
+                                       unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
+                                       int trace_tile, mpp_step_out *out, mpp_proposal *props) {
+#define GO(W, L) return launch_spec<W, L>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props, occ)
   if (lanes == 0) {
     switch (spec) { case 1: GO(1, 0); case 2: GO(2, 0); case 4: GO(4, 0); case 8: GO(8, 0); case 16: GO(16, 0); }
   } else {

@@ -16,7 +16,7 @@ from .energies import ModelDesc
 from .kernels import KernelDesc
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmppgpu.so")
+LIB_PATH = os.environ.get("MPP_LIB_PATH") or os.path.join(_HERE, "libmppgpu.so")   # override: diagnostic builds only
 
 MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 8
 
@@ -169,7 +169,7 @@ class MppContext:
     """One GPU context holding ``n_tiles`` tiles of equal shape (thin, 1:1 over the C ABI)."""
 
     def __init__(self, device: int = 0, point_capacity: Optional[int] = None, cell_capacity: Optional[int] = None,
-                 spec_waves: Optional[int] = None, spec_lanes: Optional[int] = None):
+                 spec_waves: Optional[int] = None, spec_lanes: Optional[int] = None, replicas: Optional[int] = None):
         self._L = load_library()
         h = C.c_void_p()
         rc = self._L.mpp_create(int(device), C.byref(h))
@@ -189,6 +189,8 @@ class MppContext:
             self.set_option("spec_waves", spec_waves)
         if spec_lanes is not None:
             self.set_option("spec_lanes", spec_lanes)
+        if replicas is not None:
+            self.set_option("replicas", replicas)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -245,7 +247,7 @@ class MppContext:
         self._check(self._L.mpp_set_maps(self._h, T, H, W, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]),
                                          1 if on_device else 0))
         self._keep = arrs if on_device else []
-        self.n_tiles, self.shape = T, (H, W)
+        self.n_tiles, self.shape = self.get_option("n_chains"), (H, W)     # = T * replicas
 
     def set_model(self, desc: ModelDesc, mappings):
         m, mp = model_struct(desc), mappings_struct(mappings)
