@@ -682,7 +682,8 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
 #pragma clang loop unroll(disable)
     for (int k = 0; k < 3; ++k) {
       int cls;
-      d *= row_prob(c, k, row, col, 0, true, u32d(k == 0 ? w[5] : (k == 1 ? w[6] : w[7])), &cls);
+      const uint32_t w5 = w[5], w6 = w[6], w7 = w[7];
+      d *= row_prob(c, k, row, col, 0, true, u32d(k == 0 ? w5 : (k == 1 ? w6 : w7)), &cls);
       double val = c.L.edges[k * MPP_NCLASS + cls];
       if (k == 0) r.as = val; else if (k == 1) r.ar = val; else r.aa = val;
     }
@@ -699,8 +700,10 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   if (k == MPP_K_UDEATH || k == MPP_K_DDEATH) return;
   r.has_add = 1;
   double z0 = 0.0, z1 = 0.0;
-  if (k == MPP_K_GTRANS || k == MPP_K_GTRANSF)       // words (3,4) for the translation, (4,5) for the mark transform
-    box_muller(k == MPP_K_GTRANS ? w[3] : w[4], k == MPP_K_GTRANS ? w[4] : w[5], &z0, &z1);
+  if (k == MPP_K_GTRANS || k == MPP_K_GTRANSF) {     // words (3,4) for the translation, (4,5) for the mark transform
+    const uint32_t w3 = w[3], w4 = w[4], w5 = w[5];
+    box_muller(k == MPP_K_GTRANS ? w3 : w4, k == MPP_K_GTRANS ? w4 : w5, &z0, &z1);
+  }
   if (k == MPP_K_GTRANS) {
     double d0 = P->kern.sigma_trans * z0, d1 = P->kern.sigma_trans * z1;
     int nx = (int)((double)q.x + d0), ny = (int)((double)q.y + d1);

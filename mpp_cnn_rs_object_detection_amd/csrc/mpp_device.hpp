@@ -193,12 +193,19 @@ __device__ __forceinline__ int value_to_class_tab(const DevParams *P, const doub
 __device__ __forceinline__ int value_to_class(const DevParams *P, int k, double v) {
   return value_to_class_tab(P, P->maps.edges[k], k, v);
 }
-__device__ __forceinline__ double mark_of(const Rect &q, int k) { return k == 0 ? q.s : (k == 1 ? q.r : q.a); }
+// (values first, then the choice: a conditional over the lvalues becomes a pointer phi and pins the struct in scratch)
+__device__ __forceinline__ double mark_of(const Rect &q, int k) {
+  const double s = q.s, r = q.r, a = q.a;
+  return k == 0 ? s : (k == 1 ? r : a);
+}
 __device__ __forceinline__ void set_mark(Rect &q, int k, double v) {
-  if (k == 0) q.s = v; else if (k == 1) q.r = v; else q.a = v;
+  const double s = q.s, r = q.r, a = q.a;
+  q.s = k == 0 ? v : s; q.r = k == 1 ? v : r; q.a = k == 2 ? v : a;
 }
 __device__ __forceinline__ const float *mark_row(const DevParams *P, const TileRef &t, int k, int x, int y) {
-  return t.m[k] + ((size_t)x * P->W + y) * MPP_NCLASS;
+  const float *m0 = t.m[0], *m1 = t.m[1], *m2 = t.m[2];
+  const float *b = k == 0 ? m0 : (k == 1 ? m1 : m2);   // no runtime-indexed private array
+  return b + ((size_t)x * P->W + y) * MPP_NCLASS;
 }
 
 // one unit energy term of a rectangle; `edges` = [3][32] table (HBM or LDS copy)
