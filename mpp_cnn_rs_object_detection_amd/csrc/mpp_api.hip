@@ -558,7 +558,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
   const int occ = (grid >= 1024) ? 2 : 1;
-  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, c->dp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
+  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
                              d_tape, trace_tile, d_out, d_props));
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));
   HIPCHK(c, hipEventSynchronize(c->ev1));

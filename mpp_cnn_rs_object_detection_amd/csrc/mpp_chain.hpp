@@ -35,6 +35,7 @@
 // diagnostic build only: cycles per phase of wave 0, summed over the launch (never in the product build)
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_prof3[16];
+__device__ unsigned long long g_prof2[16];
 #define PROF_T0() unsigned long long pt_ = clock64()
 #define PROF_ADD(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof_[i] += n_ - pt_; pt_ = n_; } while (0)
 #else
@@ -218,6 +219,9 @@ __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, cons
   while (m) {
     int rank = __popcll(m & ((1ull << c.lane) - 1ull));
     if (need && rank < CLIP_SLOTS) {
+#ifdef MPP_PROFILE
+      if (c.wave == 0) atomicAdd(&g_clip_count, 1ull);
+#endif
       double ax[4], ay[4], bx[4], by[4];
       if (u_first) { geo_corners(u, ax, ay); geo_corners(v, bx, by); }
       else { geo_corners(v, ax, ay); geo_corners(u, bx, by); }
@@ -252,6 +256,9 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
   int ci, cj;
   cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
   double acc = 0.0;
+#ifdef MPP_PROFILE
+  if (c.wave == 0) atomicAdd(&g_prof2[10], 1ull);
+#endif
   for (int di = -1; di <= 1; ++di)
     for (int dj = -1; dj <= 1; ++dj) {
       int i = ci + di, j = cj + dj;
@@ -285,10 +292,13 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
 // (slot, new0, new1) so that an accepted step is applied without re-evaluation;
 // *n_stash > STASH means the stash overflowed.  With APPLY the caches are updated directly.
 #ifdef MPP_PROFILE
-#define DPROF(i)
-__device__ unsigned long long g_prof2[16];
+#define DPROF_T0() unsigned long long dt_ = clock64()
+#define DPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0) atomicAdd(&g_prof2[i], n_ - dt_); dt_ = n_; } while (0)
+#define DCOUNT(i, v) do { if (c.wave == 0 && c.lane == 0) atomicAdd(&g_prof2[i], (unsigned long long)(v)); } while (0)
 #else
+#define DPROF_T0()
 #define DPROF(i)
+#define DCOUNT(i, v)
 #endif
 // `apply`: write the changed reductions straight into the caches instead of the stash (used for the rare
 // step whose neighbour updates do not fit the stash; see the kernel's "apply round").
@@ -298,6 +308,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   const Lds &L = c.L;
   const int np = P->model.n_pair;
   const bool has_rem = rem >= 0;
+  DPROF_T0();
   Geo2 gr;
   Rect rr;
   if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
@@ -322,6 +333,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
 #pragma unroll
   for (int k = 0; k < 18; ++k) M += __builtin_amdgcn_readlane(my_cnt, k);
 
+  DPROF(0); DCOUNT(9, M); DCOUNT(11, 1);
   double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
   bool any_changed = false, any_a = false;
   int stash_n = 0;
@@ -395,6 +407,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     }
     stash_n += __popcll(cm);
   }
+  DPROF(1);
   // combine the few lanes that contribute, in ascending lane order (deterministic, wave-uniform result)
   double sum_de = 0.0, ra0 = 0.0, ra1 = 0.0;
   unsigned long long cm = __ballot(any_changed);
@@ -415,6 +428,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   double dE = sum_de;
   if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra0, ra1));
   if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  DPROF(4);
   return dE;
 }
 
@@ -512,6 +526,7 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
   const Lds &L = c.L;
   const int np = P->model.n_pair;
   const bool has_rem = rem >= 0;
+  DPROF_T0();
   Geo2 gr;
   Rect rr;
   if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
@@ -583,6 +598,7 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
   double dE = sum_de;
   if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra[0], ra[1]));
   if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  DPROF(4);
   return dE;
 }
 

@@ -9,13 +9,17 @@
 // wave per SIMD; throughput runs over many tiles ask for OCC = 2 (256 VGPRs, a few spills) so that two chains
 // share a SIMD and hide each other's latencies.
 template <int WAVES, int LPW, bool DIAG, int OCC>
-__global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams *P, const TileRef *tiles, int tile0,
+__global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
                                                                   long long n_steps, unsigned long long seed,
                                                                   unsigned int chain0, const mpp_proposal *tape,
                                                                   int trace_tile, mpp_step_out *out,
                                                                   mpp_proposal *props) {
   constexpr bool LANE = LPW > 0;
   constexpr int SPEC = LANE ? WAVES * LPW : WAVES;
+  // the parameter block travels BY VALUE: it then lives in the kernel-argument segment (constant address space),
+  // so every P->field is a scalar load the compiler may cache and hoist, not a vector-memory load in the
+  // dependency chain of the step
+  const DevParams *P = &Pv;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = tile0 + blockIdx.x;
   Chain c;
@@ -309,7 +313,7 @@ static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevP
   hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC>), dim3(grid), dim3(WAVE * WAVES), lds, st, P, tiles, tile0,
+  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
                      n_steps, seed, chain0, tape, trace_tile, out, props);
   return hipGetLastError();
 }
