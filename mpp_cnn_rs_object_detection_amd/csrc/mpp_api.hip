@@ -335,10 +335,11 @@ static int push_state(mpp_ctx *c) {
     for (int t = 0; t < c->n_tiles; ++t) {
       TileRef &r = c->h_tiles[t];
       const size_t m = (size_t)(t % c->n_maps);                    // replica chains share their tile's maps
-      r.det = c->det + m * hw;
-      for (int k = 0; k < 3; ++k) r.m[k] = c->m[k] + m * hw * MPP_NCLASS;
-      r.rowpart = c->rowpart + m * hw; r.rowbase = c->rowbase + m * (c->H + 1);
-      r.boxsum = c->boxsum + m * hw;
+      r.det = (const MPP_GLOBAL float *)(c->det + m * hw);
+      for (int k = 0; k < 3; ++k) r.m[k] = (const MPP_GLOBAL float *)(c->m[k] + m * hw * MPP_NCLASS);
+      r.rowpart = (const MPP_GLOBAL double *)(c->rowpart + m * hw);
+      r.rowbase = (const MPP_GLOBAL double *)(c->rowbase + m * (c->H + 1));
+      r.boxsum = (const MPP_GLOBAL double *)(c->boxsum + m * hw);
       r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;

@@ -38,13 +38,21 @@ struct DevParams {
   double inv_step[3];   // 32 / (vmax - vmin)
 };
 
+// Pointers that are read back from a struct in memory carry no address space, and the device code would use
+// flat loads for them; in device compilation the score-map pointers are declared global (same size and layout).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MPP_GLOBAL __attribute__((address_space(1)))
+#else
+#define MPP_GLOBAL
+#endif
+
 // per-tile device pointers
 struct TileRef {
-  const float *det;
-  const float *m[3];
-  const double *rowpart;   // [H][W] inclusive partial sums of det within each row
-  const double *rowbase;   // [H+1] exclusive prefix of row totals; rowbase[H] = sum(det)
-  const double *boxsum;    // [H][W] sum of det over the (2*max_delta+1)^2 window clipped to the tile
+  const MPP_GLOBAL float *det;
+  const MPP_GLOBAL float *m[3];
+  const MPP_GLOBAL double *rowpart;   // [H][W] inclusive partial sums of det within each row
+  const MPP_GLOBAL double *rowbase;   // [H+1] exclusive prefix of row totals; rowbase[H] = sum(det)
+  const MPP_GLOBAL double *boxsum;    // [H][W] sum of det over the (2*max_delta+1)^2 window clipped to the tile
   // point configuration, dense slots (capacity cap)
   int32_t *px, *py;
   double *ps, *pr, *pa;
