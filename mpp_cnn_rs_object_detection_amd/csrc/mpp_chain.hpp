@@ -362,8 +362,8 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       for (int p = 0; p < np; ++p) {
         const mpp_pair_term &pt = P->model.pair[p];
         const double ov = p == 0 ? oldv[0] : oldv[1];
-        double nv = ov;
-        bool slow = false;
+        double nv = ov, v_add = 0.0;
+        bool carries = false, got_add = false;
         // which = 0: against the removed point (is it the one carrying u's extremum?)
         // which = 1: against the added point (it may become u's new extremum)
 #pragma clang loop unroll(disable)
@@ -374,16 +374,23 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
           const Rect rv = which == 0 ? rr : ar;
           const bool uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
           const double v = pair_value(c, pt, gu, gv, uf, which == 0 ? d2r : d2a);
-          if (which == 0) slow = (v == ov);
+          if (which == 0) carries = (v == ov);
           else {
             double &rap = p == 0 ? ra[0] : ra[1];
             rap = reduce2(pt.reduce, rap, v);
-            nv = reduce2(pt.reduce, nv, v);
+            v_add = v; got_add = true;
             any_a = true;
           }
         }
-        // a neighbour that loses its extremum is re-reduced over its own 3x3 cells (in its lane)
-        if (slow) nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+        if (carries) {
+          // u loses the neighbour that carried its extremum.  Every other neighbour is no more extreme than `ov`,
+          // so an added value at least as extreme IS the new extremum (exactly); otherwise u is re-reduced over
+          // its own 3x3 cells (in its lane)
+          const bool dominates = got_add && (pt.reduce == MPP_REDUCE_MAX ? v_add >= ov : v_add <= ov);
+          nv = dominates ? v_add : rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+        } else if (got_add) {
+          nv = reduce2(pt.reduce, ov, v_add);
+        }
         if (p == 0) newv[0] = nv; else newv[1] = nv;
       }
     }
@@ -568,13 +575,16 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
             bool uf = slot_first(L, u, gu.g, rr.x, rr.y, rr.s, rr.r, rr.a);
             if (pair_value(c, pt, gu, gr, uf, d2r) == oldv[p]) slow = true;     // the removed point carries u's extremum
           }
+          double v_a = 0.0;
           if (in_a) {
             bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
-            double v_a = pair_value(c, pt, gu, ag, uf, d2a);
+            v_a = pair_value(c, pt, gu, ag, uf, d2a);
             ra[p] = reduce2(pt.reduce, ra[p], v_a);
             nv = reduce2(pt.reduce, nv, v_a);
           }
-          if (slow) nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+          // (an added value at least as extreme as the lost extremum is the new extremum: no re-reduction)
+          if (slow && !(in_a && (pt.reduce == MPP_REDUCE_MAX ? v_a >= oldv[p] : v_a <= oldv[p])))
+            nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
           newv[p] = nv;
         }
         if (newv[0] != oldv[0] || newv[1] != oldv[1]) {
