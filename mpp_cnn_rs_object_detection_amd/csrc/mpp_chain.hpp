@@ -317,38 +317,51 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
   if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
 
-  // ---- the 3x3 cells around the removed and the added point: lanes 0..17 own one cell each
+  // ---- the 3x3 cells around the removed and the added point.  Lane 3k+e (k < 18, e < 3) owns entry e of cell k:
+  // with at most 3 points in each of the 18 cells (the usual case) every candidate neighbour has its lane
+  // without any cross-lane traffic.  Fuller cells fall back to a flattened index space over all entries.
   int my_cell = -1;
-  if (c.lane < 18) {
-    bool second = c.lane >= 9;
-    int k = second ? c.lane - 9 : c.lane;
+  const int ck = c.lane / 3, ce = c.lane - 3 * ck;
+  if (ck < 18) {
+    bool second = ck >= 9;
+    int k = second ? ck - 9 : ck;
     int i = (second ? cia : cir) + k / 3 - 1, j = (second ? cja : cjr) + k % 3 - 1;
     bool ok = second ? has_add : has_rem;
     if (ok && second && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) ok = false;   // already listed
     if (ok && i >= 0 && i < P->nx && j >= 0 && j < P->ny) my_cell = j + i * P->ny;
   }
   const int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
-  // flattened candidate index space: cell k covers [lo_k, lo_k + cnt_k)  (wave-uniform, scalar registers)
-  int M = 0;
+  const bool direct = __ballot(my_cnt > 3) == 0ull;
+  int M = WAVE;                 // direct: one pass
+  if (!direct) {
+    // flattened candidate index space: cell k covers [lo_k, lo_k + cnt_k)  (wave-uniform, scalar registers)
+    M = 0;
 #pragma unroll
-  for (int k = 0; k < 18; ++k) M += __builtin_amdgcn_readlane(my_cnt, k);
+    for (int k = 0; k < 18; ++k) M += __builtin_amdgcn_readlane(my_cnt, 3 * k);
+  }
 
   DPROF(0); DCOUNT(9, M); DCOUNT(11, 1);
   double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
   bool any_changed = false, any_a = false;
   int stash_n = 0;
   for (int base = 0; base < M; base += WAVE) {
-    const int j = base + c.lane;
-    int my_lo = 0, my_base = 0, lo = 0;
+    int my_base = my_cell * P->cell_cap, my_e = ce;
+    bool active = ce < my_cnt;
+    if (!direct) {
+      const int j = base + c.lane;
+      int my_lo = 0, lo = 0;
+      my_base = 0;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      int cnt_k = __builtin_amdgcn_readlane(my_cnt, k);
-      int cell_k = __builtin_amdgcn_readlane(my_cell, k);
-      if (j >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
-      lo += cnt_k;
+      for (int k = 0; k < 18; ++k) {
+        int cnt_k = __builtin_amdgcn_readlane(my_cnt, 3 * k);
+        int cell_k = __builtin_amdgcn_readlane(my_cell, 3 * k);
+        if (j >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+        lo += cnt_k;
+      }
+      active = j < M;
+      my_e = j - my_lo;
     }
-    bool active = j < M;
-    const int u = active ? (int)L.cell_items[my_base + (j - my_lo)] : 0;
+    const int u = active ? (int)L.cell_items[my_base + my_e] : 0;
     if (active && u == rem) active = false;
     Geo2 gu;
     double oldv[2] = {0.0, 0.0}, newv[2] = {0.0, 0.0};
