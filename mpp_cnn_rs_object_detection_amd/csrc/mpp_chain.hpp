@@ -222,9 +222,13 @@ __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, cons
 #ifdef MPP_PROFILE
       if (c.wave == 0) atomicAdd(&g_clip_count, 1ull);
 #endif
+      // (the empty asm keeps the corner arithmetic inside this rarely taken branch: the compiler would otherwise
+      // hoist and speculate it for every candidate)
+      Geo uu = u, vv = v;
+      asm volatile("" : "+v"(uu.ca), "+v"(uu.sa), "+v"(vv.ca), "+v"(vv.sa));
       double ax[4], ay[4], bx[4], by[4];
-      if (u_first) { geo_corners(u, ax, ay); geo_corners(v, bx, by); }
-      else { geo_corners(v, ax, ay); geo_corners(u, bx, by); }
+      if (u_first) { geo_corners(uu, ax, ay); geo_corners(vv, bx, by); }
+      else { geo_corners(vv, ax, ay); geo_corners(uu, bx, by); }
       area = clip_area_lds(c.L.clip + ((size_t)c.wave * CLIP_SLOTS + rank) * 32, ax, ay, bx, by) / (mn + AREA_EPS);
       need = false;
     }
@@ -239,8 +243,8 @@ __device__ __forceinline__ double pair_value(const Chain &c, const mpp_pair_term
   switch (pt.kind) {
     case MPP_P_OVERLAP: return overlap_energy_chain(c, u.g, v.g, u_first, u.rad, v.rad, (double)d2);
     case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
-    case MPP_P_DIST_LE: return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0;
-    case MPP_P_DIST_LT: return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0;
+    case MPP_P_DIST_LE: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0; }   // (not speculated)
+    case MPP_P_DIST_LT: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0; }
   }
   return 0.0;
 }
