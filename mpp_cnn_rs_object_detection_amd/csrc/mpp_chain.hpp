@@ -230,6 +230,9 @@ __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, cons
       if (u_first) { geo_corners(uu, ax, ay); geo_corners(vv, bx, by); }
       else { geo_corners(vv, ax, ay); geo_corners(uu, bx, by); }
       area = clip_area_lds(c.L.clip + ((size_t)c.wave * CLIP_SLOTS + rank) * 32, ax, ay, bx, by) / (mn + AREA_EPS);
+#ifdef MPP_PROFILE
+      if (c.wave == 0 && area == 0.0) atomicAdd(&g_prof2[12], 1ull);
+#endif
       need = false;
     }
     m = __ballot(need);

@@ -163,6 +163,105 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
     if (c.wave == 0) {
       int committed = 0, cur_n = n;
       double Tc = *(double *)(L.sh + 4);
+      // commit record q (an accepted step that changes the configuration); returns true when the round must end
+      // after it (population or index->slot map changed, or an error)
+      auto commit_one = [&](const Rec &q, int w) -> bool {
+        if (!apply_round && c.lane < q.n_stash) {
+          int u = L.stash_slot[w * STASH + c.lane];
+          L.red0[u] = L.stash_v0[w * STASH + c.lane];
+          L.red1[u] = L.stash_v1[w * STASH + c.lane];
+        }
+        wave_lds_fence();
+        bool stop = false;
+        if (q.has_rem && q.has_add) {                      // move / transform: same slot
+          int ci, cj;
+          int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
+          if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &err); }
+          write_slot(c, q.tslot, q);
+        } else if (q.has_rem) {                            // death: last index takes the hole
+          int ci, cj;
+          cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
+          if (c.lane == 0) {
+            unsigned short last = L.order[cur_n - 1];
+            L.order[cur_n - 1] = (unsigned short)q.tslot;
+            L.order[q.tidx] = last;
+          }
+          cur_n -= 1;
+        } else {                                           // birth: next free slot
+          if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; }
+          else {
+            int slot = L.order[cur_n], ci, cj;
+            cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &err);
+            write_slot(c, slot, q);
+            cur_n += 1;
+          }
+        }
+        wave_lds_fence();
+        // which later speculative steps are still trustworthy?
+        if (SPEC > 1) {
+          if (!(q.has_rem && q.has_add)) stop = true;      // n or the index->slot map changed
+          else {
+            // lane w2 judges record w2: it is stale if it touches the same slot or anything within
+            // 2*max_inter of the positions this step changed
+            int w2 = c.lane;
+            if (w2 > w && w2 < SPEC) {
+              Rec &o = L.rec[w2];
+              if (o.valid) {
+                bool bad = o.has_rem && o.tslot == q.tslot;
+                int ox[2] = {o.rx, o.ax}, oy[2] = {o.ry, o.ay}, oh[2] = {o.has_rem, o.has_add};
+                int qx[2] = {q.rx, q.ax}, qy[2] = {q.ry, q.ay};
+                for (int a = 0; a < 2; ++a)
+                  for (int b = 0; b < 2; ++b)
+                    if (oh[a]) {
+                      int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
+                      if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
+                    }
+                if (bad) o.valid = 0;
+              }
+            }
+          }
+          wave_lds_fence();
+        }
+        return stop;
+      };
+      if (SPEC > 1 && !tracing) {
+        // Untraced rounds: lane w looks at record w, and the loop only visits the ACCEPTED records (about a
+        // quarter of the steps); rejected ones cost nothing but their temperature update.
+        const long long left = n_steps - done;
+        const int lim = left < (long long)SPEC ? (int)left : SPEC;
+        auto low = [](int k) -> unsigned long long { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); };
+        const unsigned long long lim_mask = low(lim);
+        const bool in = c.lane < lim;
+        const bool acc = in && L.rec[in ? c.lane : 0].accepted && (L.rec[in ? c.lane : 0].has_rem || L.rec[in ? c.lane : 0].has_add);
+        const unsigned long long acc_mask = __ballot(acc);
+        int cur = 0;
+        while (true) {
+          const unsigned long long bad_mask = ~__ballot(in && L.rec[in ? c.lane : 0].valid) & lim_mask;
+          const int first_bad = bad_mask ? __ffsll((long long)bad_mask) - 1 : lim;
+          const unsigned long long todo = acc_mask & ~low(cur) & low(first_bad);
+          if (!todo) {
+            committed = first_bad;
+            if (first_bad < lim) {
+              const int kq = L.rec[first_bad].kernel;
+              if (kq == -1) err = ERR_BAD_TARGET;
+              else if (kq <= -3) err = -2 - kq;
+              // otherwise: invalidated by an earlier accept of this round -> re-evaluated next round
+            }
+            break;
+          }
+          const int w = __ffsll((long long)todo) - 1;
+          const Rec q = L.rec[w];
+          if (q.n_stash > STASH && !apply_round) {           // see the traced loop below
+            if (c.lane == 0) L.sh[6] = 1;
+            committed = w;
+            break;
+          }
+          const bool stop = commit_one(q, w);
+          cur = w + 1;
+          if (stop || err) { committed = w + 1; break; }
+        }
+        for (int i = 0; i < committed; ++i) if (Tc > T_target) Tc *= alpha;      // rjmcmc.py:158-159
+      } else {
       bool stop = false;
       for (int w = 0; w < SPEC && !stop; ++w) {
         if (done + w >= n_steps) break;
@@ -180,61 +279,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
             if (c.lane == 0) L.sh[6] = 1;
             break;
           }
-          if (!apply_round && c.lane < q.n_stash) {
-            int u = L.stash_slot[w * STASH + c.lane];
-            L.red0[u] = L.stash_v0[w * STASH + c.lane];
-            L.red1[u] = L.stash_v1[w * STASH + c.lane];
-          }
-          wave_lds_fence();
-          if (q.has_rem && q.has_add) {                      // move / transform: same slot
-            int ci, cj;
-            int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
-            if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &err); }
-            write_slot(c, q.tslot, q);
-          } else if (q.has_rem) {                            // death: last index takes the hole
-            int ci, cj;
-            cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
-            if (c.lane == 0) {
-              unsigned short last = L.order[cur_n - 1];
-              L.order[cur_n - 1] = (unsigned short)q.tslot;
-              L.order[q.tidx] = last;
-            }
-            cur_n -= 1;
-          } else {                                           // birth: next free slot
-            if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; }
-            else {
-              int slot = L.order[cur_n], ci, cj;
-              cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &err);
-              write_slot(c, slot, q);
-              cur_n += 1;
-            }
-          }
-          wave_lds_fence();
-          // which later speculative steps are still trustworthy?
-          if (SPEC > 1) {
-            if (!(q.has_rem && q.has_add)) stop = true;      // n or the index->slot map changed
-            else {
-              // lane w2 judges record w2: it is stale if it touches the same slot or anything within
-              // 2*max_inter of the positions this step changed
-              int w2 = c.lane;
-              if (w2 > w && w2 < SPEC) {
-                Rec &o = L.rec[w2];
-                if (o.valid) {
-                  bool bad = o.has_rem && o.tslot == q.tslot;
-                  int ox[2] = {o.rx, o.ax}, oy[2] = {o.ry, o.ay}, oh[2] = {o.has_rem, o.has_add};
-                  int qx[2] = {q.rx, q.ax}, qy[2] = {q.ry, q.ay};
-                  for (int a = 0; a < 2; ++a)
-                    for (int b = 0; b < 2; ++b)
-                      if (oh[a]) {
-                        int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
-                        if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
-                      }
-                  if (bad) o.valid = 0;
-                }
-              }
-            }
-            wave_lds_fence();
-          }
+          stop = commit_one(q, w);
         }
         if (tracing && c.lane == 0) {
           long long idx = done + w;
@@ -255,6 +300,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         if (Tc > T_target) Tc *= alpha;                      // rjmcmc.py:158-159
         committed += 1;
         if (err) break;
+      }
       }
       if (c.lane == 0) {
         L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; *(double *)(L.sh + 4) = Tc;
