@@ -206,6 +206,57 @@ __device__ inline double clip_area_lds(double *buf, const double *sx, const doub
   }
   return 0.5 * fabs(s);
 }
+// The same clipper with the whole wave on ONE polygon pair (uniform control flow required): lane i owns
+// vertex i of the current polygon, the output positions come from two ballots, the shoelace sum is accumulated in
+// vertex order.  Every vertex goes through exactly the arithmetic of clip_area()/clip_area_lds(), so the area is
+// bit-identical; a clip costs ~4 short stages instead of ~20 dependent single-lane vertex steps.
+__device__ inline double clip_area_wave(const Chain &c, const double *sx, const double *sy, const double *cx,
+                                        const double *cy) {
+  double *buf = c.L.clip + (size_t)c.wave * CLIP_SLOTS * 32;
+  double *ax = buf, *ay = buf + 8, *bx = buf + 16, *by = buf + 24;
+  if (c.lane < 4) {
+    const int l = c.lane;
+    ax[l] = l == 0 ? sx[0] : (l == 1 ? sx[1] : (l == 2 ? sx[2] : sx[3]));
+    ay[l] = l == 0 ? sy[0] : (l == 1 ? sy[1] : (l == 2 ? sy[2] : sy[3]));
+  }
+  wave_lds_fence();
+  const unsigned long long below = (1ull << c.lane) - 1ull;
+  int na = 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (na <= 0) break;
+    const double x0 = cx[e], y0 = cy[e], x1 = cx[(e + 1) & 3], y1 = cy[(e + 1) & 3];
+    const double ex = x1 - x0, ey = y1 - y0;
+    const bool valid = c.lane < na;
+    const int ii = valid ? c.lane : 0, pi = ii == 0 ? na - 1 : ii - 1;
+    const double qx = ax[ii], qy = ay[ii], px = ax[pi], py = ay[pi];
+    const double sq = ex * (qy - y0) - ey * (qx - x0), sp = ex * (py - y0) - ey * (px - x0);
+    const bool e_int = valid && (sq >= 0 ? sp < 0 : sp >= 0), e_q = valid && sq >= 0;
+    const unsigned long long mi = __ballot(e_int), mq = __ballot(e_q);
+    int off = __popcll(mi & below) + __popcll(mq & below);
+    if (e_int) {
+      if (off < 8) {
+        double t = sp / (sp - sq);
+        bx[off] = px + t * (qx - px); by[off] = py + t * (qy - py);
+      }
+      ++off;
+    }
+    if (e_q && off < 8) { bx[off] = qx; by[off] = qy; }
+    int nb = __popcll(mi) + __popcll(mq);
+    na = nb < 8 ? nb : 8;
+    double *tx = ax, *ty = ay;
+    ax = bx; ay = by; bx = tx; by = ty;
+    wave_lds_fence();
+  }
+  if (na < 3) return 0.0;
+  const bool valid = c.lane < na;
+  const int ii = valid ? c.lane : 0, jj = ii + 1 == na ? 0 : ii + 1;
+  const double term = ax[ii] * ay[jj] - ax[jj] * ay[ii];
+  double s = 0.0;
+  for (int i = 0; i < na; ++i) s += readlane_d(term, i);
+  wave_lds_fence();
+  return 0.5 * fabs(s);
+}
 // RectangleOverlapEnergy for the chain: lanes that really have to clip (circumscribed circles meet) take turns
 // on the wave's CLIP_SLOTS polygon buffers.  Works in divergent code too: the ballots only see active lanes.
 __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, const Geo &v, bool u_first, double ru,
@@ -240,6 +291,16 @@ __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, cons
   return area;
 }
 
+// pair energy of (u, v) when the overlap value has been computed beforehand (eval_delta's uniform clip phase)
+__device__ __forceinline__ double pair_value_pre(const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v, int d2, double ovl) {
+  switch (pt.kind) {
+    case MPP_P_OVERLAP: return ovl;
+    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
+    case MPP_P_DIST_LE: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0; }
+    case MPP_P_DIST_LT: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0; }
+  }
+  return 0.0;
+}
 // pair energy of (u, v); d2 = squared centre distance (integer valued)
 __device__ __forceinline__ double pair_value(const Chain &c, const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v,
                                              bool u_first, int d2) {
@@ -371,13 +432,63 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     const int u = active ? (int)L.cell_items[my_base + my_e] : 0;
     if (active && u == rem) active = false;
     Geo2 gu;
+    gu.g.x = gu.g.y = 0; gu.g.hl = gu.g.hw = gu.g.ca = gu.g.sa = 0.0; gu.rad = 0.0;
     double oldv[2] = {0.0, 0.0}, newv[2] = {0.0, 0.0};
+    int d2r = 0, d2a = 0;
     if (active) {
       gu = load_geo(L, u);
       oldv[0] = L.red0[u]; oldv[1] = L.red1[u];
-      int d2r = 0, d2a = 0;
       if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
       if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
+    }
+    // ---- overlap terms first, in uniform control flow: every (candidate, removed/added) pair whose circumscribed
+    // circles meet is clipped by the whole wave, one pair after the other (there are ~0.2 of them per step)
+    double ovl_r0 = 0.0, ovl_a0 = 0.0, ovl_r1 = 0.0, ovl_a1 = 0.0;
+#pragma clang loop unroll(disable)
+    for (int p = 0; p < np; ++p) {
+      if (P->model.pair[p].kind != MPP_P_OVERLAP) continue;
+#pragma clang loop unroll(disable)
+      for (int which = 0; which < 2; ++which) {
+        const double ov = p == 0 ? oldv[0] : oldv[1];
+        bool need = active && (which == 0 ? (has_rem && d2r <= P->maxd2[p] && ov != 0.0) : (has_add && d2a <= P->maxd2[p]));
+        const Geo2 gv = which == 0 ? gr : ag;
+        const Rect rv = which == 0 ? rr : ar;
+        const double B = geo_area(gv.g);
+        double mn = 0.0;
+        bool uf = false;
+        if (need) {
+          const double A = geo_area(gu.g), reach = gu.rad + gv.rad, d2 = (double)(which == 0 ? d2r : d2a);
+          mn = A < B ? A : B;
+          need = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
+          if (need) uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
+        }
+        double val = 0.0;
+        unsigned long long m = __ballot(need);
+        while (m) {
+          const int src = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          Geo bu;
+          bu.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.y = __builtin_amdgcn_readlane(gu.g.y, src);
+          bu.hl = readlane_d(gu.g.hl, src); bu.hw = readlane_d(gu.g.hw, src);
+          bu.ca = readlane_d(gu.g.ca, src); bu.sa = readlane_d(gu.g.sa, src);
+          const bool u_first = __builtin_amdgcn_readlane((int)uf, src) != 0;
+          DCOUNT(8, 1);
+          double ux[4], uy[4], vx[4], vy[4];
+          geo_corners(bu, ux, uy); geo_corners(gv.g, vx, vy);
+          double sx[4], sy[4], cx[4], cy[4];          // subject = the smaller rectangle in the canonical order
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            sx[i] = u_first ? ux[i] : vx[i]; sy[i] = u_first ? uy[i] : vy[i];
+            cx[i] = u_first ? vx[i] : ux[i]; cy[i] = u_first ? vy[i] : uy[i];
+          }
+          const double area = clip_area_wave(c, sx, sy, cx, cy);
+          if (c.lane == src) val = area / (mn + AREA_EPS);
+        }
+        if (p == 0) { if (which == 0) ovl_r0 = val; else ovl_a0 = val; }
+        else { if (which == 0) ovl_r1 = val; else ovl_a1 = val; }
+      }
+    }
+    if (active) {
 #pragma clang loop unroll(disable)
       for (int p = 0; p < np; ++p) {
         const mpp_pair_term &pt = P->model.pair[p];
@@ -391,9 +502,8 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
           const bool in = which == 0 ? (has_rem && d2r <= P->maxd2[p] && ov != 0.0) : (has_add && d2a <= P->maxd2[p]);
           if (!in) continue;
           const Geo2 gv = which == 0 ? gr : ag;
-          const Rect rv = which == 0 ? rr : ar;
-          const bool uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
-          const double v = pair_value(c, pt, gu, gv, uf, which == 0 ? d2r : d2a);
+          const double pre = p == 0 ? (which == 0 ? ovl_r0 : ovl_a0) : (which == 0 ? ovl_r1 : ovl_a1);
+          const double v = pair_value_pre(pt, gu, gv, which == 0 ? d2r : d2a, pre);
           if (which == 0) carries = (v == ov);
           else {
             double &rap = p == 0 ? ra[0] : ra[1];
