@@ -167,6 +167,13 @@ int mpp_posnet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const floa
                         double div_b, float *det);
 int mpp_shapenet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *logits, float *marks);
 
+/* IoU matrix of convex quadrilaterals for the DOTA task-1 evaluation: a [n][8], b [m][8] (x1 y1 .. x4 y4, either
+ * orientation) -> out [n][m] = |A_i n B_j| / (|A_i| + |B_j| - |A_i n B_j|), or -1 where the axis-aligned extents
+ * (inclusive-pixel +1 convention) do not overlap.  Stands in for `polyiou.iou_poly` and the hbb pre-filter of
+ * DOTA_devkit dota_evaluation_task1.voc_eval as called from metrics/dota_eval.py:37-47 (devkit not vendored,
+ * README.md:22-30).  on_device != 0: a, b, out are device pointers. */
+int mpp_quad_iou(mpp_ctx *ctx, int n, const double *a, int m, const double *b, double *out, int on_device);
+
 void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int mpp_abi_version(void);
 

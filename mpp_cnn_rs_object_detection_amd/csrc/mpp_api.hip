@@ -14,6 +14,7 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
                                        const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
                                        unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
+extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors);
 extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -632,6 +633,30 @@ extern "C" int mpp_posnet_epilogue(mpp_ctx *c, int H, int W, int ldh, int ldw, c
   mpp_launch_posnet_epilogue(c->stream, pos_out, H, W, ldh, ldw, (float)div_w, (float)div_b, det);
   HIPCHK(c, hipGetLastError());
   return 0;
+}
+extern "C" int mpp_quad_iou(mpp_ctx *c, int n, const double *a, int m, const double *b, double *out, int on_device) {
+  if (!c || n < 0 || m < 0 || ((long long)n * m > 0 && (!a || !b || !out))) return fail(c, -1, "bad quad_iou arguments");
+  if ((long long)n * m == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (on_device) {
+    mpp_launch_quad_iou(c->stream, n, a, m, b, out);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+  }
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t sa = (size_t)n * 8 * sizeof(double), sb = (size_t)m * 8 * sizeof(double), so = (size_t)n * m * sizeof(double);
+  int rc = 0;
+  if (hipMalloc((void **)&da, sa) != hipSuccess || hipMalloc((void **)&db, sb) != hipSuccess ||
+      hipMalloc((void **)&dout, so) != hipSuccess) rc = fail(c, -2, "quad_iou: device allocation failed");
+  if (!rc && (hipMemcpyAsync(da, a, sa, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+              hipMemcpyAsync(db, b, sb, hipMemcpyHostToDevice, c->stream) != hipSuccess)) rc = fail(c, -2, "quad_iou: upload failed");
+  if (!rc) {
+    mpp_launch_quad_iou(c->stream, n, da, m, db, dout);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, dout, so, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) rc = fail(c, -2, "quad_iou: kernel or download failed");
+  }
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  return rc;
 }
 extern "C" int mpp_shapenet_epilogue(mpp_ctx *c, int H, int W, int ldh, int ldw, const float *logits, float *marks) {
   if (!c || !logits || !marks || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");

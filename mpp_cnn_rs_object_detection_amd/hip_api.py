@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library(path: Optional[str] = None):
         "mpp_last_kernel_ms": (i32, [vp, C.POINTER(dbl)]),
         "mpp_posnet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, dbl, dbl, vp]),
         "mpp_shapenet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "mpp_quad_iou": (i32, [vp, i32, vp, i32, vp, vp, i32]),
         "mpp_philox4x32": (None, [vp, vp, vp]),
         "mpp_abi_version": (i32, []),
     }
@@ -354,6 +355,15 @@ class MppContext:
     def shapenet_epilogue(self, logits, H: int, W: int, marks_out):
         ldh, ldw = int(logits.shape[-2]), int(logits.shape[-1])
         self._check(self._L.mpp_shapenet_epilogue(self._h, H, W, ldh, ldw, _ptr(logits), _ptr(marks_out)))
+
+    # -- evaluation --------------------------------------------------------------------------------
+    def quad_iou(self, a, b) -> np.ndarray:
+        """IoU matrix [n][m] of convex quads a [n][8] and b [m][8] (-1: axis-aligned extents apart)."""
+        a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1, 8))
+        b = np.ascontiguousarray(np.asarray(b, dtype=np.float64).reshape(-1, 8))
+        out = np.zeros((len(a), len(b)), np.float64)
+        self._check(self._L.mpp_quad_iou(self._h, len(a), _ptr(a), len(b), _ptr(b), _ptr(out), 0))
+        return out
 
 
 def philox(ctr, key) -> np.ndarray:

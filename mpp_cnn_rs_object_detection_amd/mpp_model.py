@@ -229,8 +229,13 @@ class MPPModel:
             print("saved dota translation")
 
     def eval(self):
-        raise NotImplementedError("the DOTA mAP evaluator (un-vendored DOTA_devkit in the reference, "
-                                  "metrics/dota_eval.py:37-38) is listed as a next step in DESIGN.md")
+        """mpp_model.py:372-387: the "vehicle" and the small-vehicle ("-SV") DOTA files written by infer()"""
+        from .dota_eval import dota_eval
+        out = {}
+        for postfix in ("", "-SV"):
+            out[postfix] = dota_eval(model_dir=self.save_path, dataset=self.dataset, subset="val", det_type="obb",
+                                     postfix=postfix, device=self.device)
+        return out
 
     def data_preview(self):
         raise NotImplementedError("figures are outside this build")

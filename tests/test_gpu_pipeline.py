@@ -161,7 +161,7 @@ def synthetic_dataset(tmp_path):
 def test_main_infer_mpp_end_to_end(synthetic_dataset, config):
     root, gt_xy = synthetic_dataset
     env = dict(os.environ, PYTHONPATH=REPO)
-    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", "infer", "-m", "mpp", "-c", config,
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", "infereval", "-m", "mpp", "-c", config,
                         "-d", "SYNTH", "-o"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     name = "mpp_hrcM" if config == "mpp_hrcM" else "mpp_log"
@@ -179,3 +179,9 @@ def test_main_infer_mpp_end_to_end(synthetic_dataset, config):
     assert len(lines) == len(centers) and all(len(ln.split()) == 10 and ln.startswith("0007 ") for ln in lines)
     assert len(open(out / "dota" / "gt" / "0007.txt").read().splitlines()) == len(gt_xy)
     assert len(res["detection_score"]) == len(centers) and min(res["detection_score"]) > 0
+    # -p infereval also ran the DOTA task-1 evaluation (metrics/dota_eval.py:16-87): one json per IoU threshold
+    for postfix in ("", "-SV"):
+        with open(out / ("dota" + postfix) / "metrics0.25.json") as f:
+            m = json.load(f)["vehicle"]
+        assert m["ap"] > 0.9 and len(m["precision"]) == len(m["recall"]) == len(centers)
+        assert os.path.exists(out / ("dota" + postfix) / "metrics0.75.json")
