@@ -141,6 +141,15 @@ int mpp_total_energy(mpp_ctx *ctx, int tile, double *energy, double *vectors_or_
  * case i removes slots rem[rem_off[i]..rem_off[i+1]) and adds rectangles add_off[i]..add_off[i+1] */
 int mpp_delta_batch(mpp_ctx *ctx, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
                     const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE);
+/* The same perturbations, but the per-point energy VECTORS (n_unit unit terms, then n_pair reductions) before and
+ * after each one instead of the combined dE: what EnergyComputeTorch.compute feeds to the torch weight model in
+ * train_energy_combination/train_ordering_criterion.py:27-40,101-118 (via energy_graph.py:139-225).
+ * Row i*stride + j of before/after ([n_cases*stride][n_unit+n_pair]) and mask ([n_cases*stride]): j < n is
+ * existing slot j, j >= n the (j-n)-th rectangle added by case i; stride >= n + additions of every case.
+ * mask: 0 untouched, 1 neighbour of a change (both rows valid), 2 removed (before only), 3 added (after only). */
+int mpp_delta_vectors(mpp_ctx *ctx, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                      const int32_t *add_off, const int32_t *add_xy, const double *add_marks, int stride,
+                      double *before, double *after, unsigned char *mask);
 /* papangelou(u, remove_u_from_point_set=True, return_energy_delta=True) of every point */
 int mpp_papangelou(mpp_ctx *ctx, int tile, double *dE);
 /* naive_detection (sample_rjmcmc.py:23-35): threshold + greedy distance-NMS, sets every tile's points */

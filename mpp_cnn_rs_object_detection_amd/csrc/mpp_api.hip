@@ -14,6 +14,10 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
                                        const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
                                        unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
+extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
+                                         int n_cases, const int32_t *rem_off, const int32_t *rem,
+                                         const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
+                                         int stride, double *before, double *after, unsigned char *mask);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors);
@@ -458,8 +462,10 @@ extern "C" int mpp_total_energy(mpp_ctx *c, int tile, double *energy, double *ve
   return 0;
 }
 
-extern "C" int mpp_delta_batch(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
-                               const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE) {
+// shared body of mpp_delta_batch (dE != NULL) and mpp_delta_vectors (before/after/mask != NULL)
+static int delta_cases(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                       const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE, int stride,
+                       double *before, double *after, unsigned char *mask) {
   int rc = check_tile(c, tile);
   if (rc) return rc;
   if ((rc = push_state(c))) return rc;
@@ -472,11 +478,21 @@ extern "C" int mpp_delta_batch(mpp_ctx *c, int tile, int n_cases, const int32_t 
   for (int i = 0; i < n_add; ++i)
     if (add_xy[2 * i] < 0 || add_xy[2 * i] >= c->H || add_xy[2 * i + 1] < 0 || add_xy[2 * i + 1] >= c->W)
       return fail(c, -5, "added point %d is outside the tile", i);
+  const int nt = c->hp.model.n_unit + c->hp.model.n_pair;
+  if (!dE) {
+    for (int i = 0; i < n_cases; ++i)
+      if (n + (add_off[i + 1] - add_off[i]) > stride)
+        return fail(c, -1, "delta_vectors: stride %d < n + additions of case %d (%d)", stride, i, n + add_off[i + 1] - add_off[i]);
+  }
   int32_t *d_ro = nullptr, *d_r = nullptr, *d_ao = nullptr, *d_axy = nullptr;
-  double *d_am = nullptr, *d_out = nullptr;
+  double *d_am = nullptr, *d_out = nullptr, *d_b = nullptr, *d_a = nullptr;
+  unsigned char *d_m = nullptr;
+  const size_t rows = dE ? 0 : (size_t)n_cases * stride;
   HIPCHK(c, dalloc(&d_ro, (size_t)n_cases + 1)); HIPCHK(c, dalloc(&d_ao, (size_t)n_cases + 1));
   HIPCHK(c, dalloc(&d_r, (size_t)n_rem)); HIPCHK(c, dalloc(&d_axy, (size_t)2 * n_add));
-  HIPCHK(c, dalloc(&d_am, (size_t)3 * n_add)); HIPCHK(c, dalloc(&d_out, (size_t)n_cases));
+  HIPCHK(c, dalloc(&d_am, (size_t)3 * n_add));
+  if (dE) HIPCHK(c, dalloc(&d_out, (size_t)n_cases));
+  else { HIPCHK(c, dalloc(&d_b, rows * nt)); HIPCHK(c, dalloc(&d_a, rows * nt)); HIPCHK(c, dalloc(&d_m, rows)); }
   hipError_t e = hipSuccess;
   auto up = [&](void *dst, const void *src, size_t bytes) {
     if (bytes && e == hipSuccess) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
@@ -485,14 +501,33 @@ extern "C" int mpp_delta_batch(mpp_ctx *c, int tile, int n_cases, const int32_t 
   up(d_r, rem, n_rem * sizeof(int32_t)); up(d_axy, add_xy, 2 * (size_t)n_add * sizeof(int32_t));
   up(d_am, add_marks, 3 * (size_t)n_add * sizeof(double));
   if (e == hipSuccess) {
-    mpp_launch_delta_batch(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, d_out);
-    e = hipMemcpyAsync(dE, d_out, n_cases * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (dE) {
+      mpp_launch_delta_batch(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, d_out);
+      e = hipMemcpyAsync(dE, d_out, n_cases * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    } else {
+      mpp_launch_delta_vectors(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, stride, d_b, d_a, d_m);
+      e = hipMemcpyAsync(before, d_b, rows * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(after, d_a, rows * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(mask, d_m, rows, hipMemcpyDeviceToHost, c->stream);
+    }
   }
   hipError_t e2 = hipStreamSynchronize(c->stream);
-  void *ptrs[] = {d_ro, d_r, d_ao, d_axy, d_am, d_out};
-  for (void *p : ptrs) (void)hipFree(p);
+  void *ptrs[] = {d_ro, d_r, d_ao, d_axy, d_am, d_out, d_b, d_a, d_m};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
   HIPCHK(c, e); HIPCHK(c, e2);
   return 0;
+}
+
+extern "C" int mpp_delta_batch(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                               const int32_t *add_off, const int32_t *add_xy, const double *add_marks, double *dE) {
+  if (!dE && n_cases > 0) return fail(c, -1, "delta_batch: dE is NULL");
+  return delta_cases(c, tile, n_cases, rem_off, rem, add_off, add_xy, add_marks, dE, 0, nullptr, nullptr, nullptr);
+}
+extern "C" int mpp_delta_vectors(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off, const int32_t *rem,
+                                 const int32_t *add_off, const int32_t *add_xy, const double *add_marks, int stride,
+                                 double *before, double *after, unsigned char *mask) {
+  if (n_cases > 0 && (!before || !after || !mask || stride <= 0)) return fail(c, -1, "bad delta_vectors arguments");
+  return delta_cases(c, tile, n_cases, rem_off, rem, add_off, add_xy, add_marks, nullptr, stride, before, after, mask);
 }
 
 extern "C" int mpp_papangelou(mpp_ctx *c, int tile, double *dE) {

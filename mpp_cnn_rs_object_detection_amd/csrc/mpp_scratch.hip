@@ -123,6 +123,61 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
   if (threadIdx.x == 0) dE[cs] = part[0];
 }
 
+// The same walk, but the per-point energy VECTORS (unit terms, then pair reductions) before and after the
+// perturbation are written out instead of being combined: the weight-learning criterion differentiates the
+// combinator on them (train_ordering_criterion.py:101-118 with EnergyComputeTorch, :27-40).
+// Row cs*stride + i: i < n existing slot i, i >= n the (i-n)-th added rectangle.
+// mask: 0 untouched, 1 neighbour of a change (both rows), 2 removed (before only), 3 added (after only).
+__global__ __launch_bounds__(256) void k_delta_vectors(const DevParams *P, const TileRef *tiles, int tile,
+                                                       const int32_t *rem_off, const int32_t *rem,
+                                                       const int32_t *add_off, const int32_t *add_xy,
+                                                       const double *add_marks, int stride, double *before,
+                                                       double *after, unsigned char *mask) {
+  TileRef t = tiles[tile];
+  const int n = *t.n, cs = blockIdx.x;
+  const int nt = P->model.n_unit + P->model.n_pair;
+  Overlay o;
+  o.n_excl = rem_off[cs + 1] - rem_off[cs]; o.excl = rem + rem_off[cs];
+  o.n_extra = add_off[cs + 1] - add_off[cs]; o.exy = add_xy + 2 * (size_t)add_off[cs];
+  o.emarks = add_marks + 3 * (size_t)add_off[cs];
+  Overlay none{0, nullptr, 0, nullptr, nullptr};
+  for (int i = threadIdx.x; i < stride; i += blockDim.x) {
+    const size_t row = (size_t)cs * stride + i;
+    double vb[MPP_MAX_UNIT + MPP_MAX_PAIR], va[MPP_MAX_UNIT + MPP_MAX_PAIR];
+    for (int k = 0; k < nt; ++k) vb[k] = va[k] = 0.0;
+    unsigned char mk = 0;
+    if (i < n) {
+      Rect u = tile_rect(t, i);
+      if (excluded(o, i)) { point_energy(P, t, n, u, i, -1, none, vb); mk = 2; }
+      else {
+        bool touched = false;
+        for (int k = 0; k < o.n_excl && !touched; ++k) {
+          double dx = (double)(u.x - t.px[o.excl[k]]), dy = (double)(u.y - t.py[o.excl[k]]);
+          touched = sqrt(dx * dx + dy * dy) <= P->max_inter;
+        }
+        for (int k = 0; k < o.n_extra && !touched; ++k) {
+          double dx = (double)(u.x - o.exy[2 * k]), dy = (double)(u.y - o.exy[2 * k + 1]);
+          touched = sqrt(dx * dx + dy * dy) <= P->max_inter;
+        }
+        if (touched) { point_energy(P, t, n, u, i, -1, none, vb); point_energy(P, t, n, u, i, -1, o, va); mk = 1; }
+      }
+    } else if (i - n < o.n_extra) {
+      point_energy(P, t, n, extra_rect(o, i - n), -1, i - n, o, va);
+      mk = 3;
+    }
+    mask[row] = mk;
+    for (int k = 0; k < nt; ++k) { before[row * nt + k] = vb[k]; after[row * nt + k] = va[k]; }
+  }
+}
+
+extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
+                                         int n_cases, const int32_t *rem_off, const int32_t *rem,
+                                         const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
+                                         int stride, double *before, double *after, unsigned char *mask) {
+  if (n_cases <= 0 || stride <= 0) return;
+  hipLaunchKernelGGL(k_delta_vectors, dim3(n_cases), dim3(256), 0, st, P, tiles, tile, rem_off, rem, add_off, add_xy,
+                     add_marks, stride, before, after, mask);
+}
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors) {
   if (n <= 0) return;

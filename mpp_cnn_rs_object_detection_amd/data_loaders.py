@@ -19,7 +19,7 @@ import numpy as np
 
 from . import mappings as _mappings
 from .custom_types import ImageWMaps
-from .paths import get_dataset_base_path, get_inference_path
+from .paths import fetch_data_paths, get_dataset_base_path, get_inference_path
 from .point_set import EPointsSet
 from .shapes import Rectangle, wla_to_sra
 
@@ -139,3 +139,51 @@ def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], ori
         for i in np.nonzero(removed)[0]:
             agg.remove(merged[i])
     return agg
+
+
+class MPPDataset:
+    """Random 256-px training patches with their ground truth (reference ``data_loaders.py:163-251`` with the
+    samplers of ``data/patch_samplers.py:38-108``): a uniformly drawn image, the patch centred on a uniformly drawn
+    pixel (weight 1/10) or on a jittered object centre (9/10, sigma 10)."""
+
+    def __init__(self, dataset: str, subset: str, position_model: str, shape_model: str, patch_size: int,
+                 patch_ids: List[int] = None, nets=None):
+        import re
+        self.dataset, self.subset, self.patch_size = dataset, subset, patch_size
+        self.position_model, self.shape_model, self.nets = position_model, shape_model, nets
+        files = fetch_data_paths(dataset, subset)
+        assert len(files["images"]) > 0
+        pat = re.compile(r"([0-9]+)\.[a-zA-z]+")
+        ids = [pat.match(os.path.split(p)[1]).group(1) for p in files["images"]]
+        if patch_ids is not None:
+            keep = {f"{i:04}" for i in patch_ids}
+            sel = [k for k, i in enumerate(ids) if i in keep]
+        else:
+            sel = list(range(len(ids)))
+        self.patches_index = [ids[k] for k in sel]
+        self.rng = np.random.default_rng(0)
+        # Upstream builds both samplers with n_patches == n_images, for which the per-image densities
+        # (count / sum) * (n_patches - n_images) + 1 are uniform (patch_samplers.py:56-58, 92-93).
+
+    def __len__(self):
+        return len(self.patches_index)
+
+    def __getitem__(self, index) -> ImageWMaps:
+        sampler = 0 if self.rng.random() < 0.1 else 1                          # MixedSampler weights [1/10, 9/10]
+        k = int(self.rng.integers(0, len(self)))
+        data = load_image_w_maps(self.patches_index[k], self.dataset, self.subset, self.position_model,
+                                 self.shape_model, nets=self.nets)
+        centers = np.asarray(data.labels["centers"])
+        if sampler == 1 and len(centers) > 0:
+            c = self.rng.normal(self.rng.choice(centers, axis=0).astype(int), 10).astype(int)
+            c = np.clip(c, (0, 0), data.shape[:2])
+        else:
+            c = self.rng.integers((0, 0), data.shape[:2])
+        ps = min(self.patch_size, data.shape[0], data.shape[1])
+        tl = np.clip((c - ps // 2).astype(int), (0, 0), (data.shape[0] - ps, data.shape[1] - ps))
+        return crop_image_w_maps(image_data=data, tl_anchor=tl, patch_size=ps)
+
+    def batches(self, batch_size: int):
+        """one epoch of lists of patches (the reference's DataLoader with ``collate_fn`` = identity)"""
+        n = len(self)
+        return [[self[i] for i in range(b, min(b + batch_size, n))] for b in range(0, n, batch_size)]

@@ -222,6 +222,22 @@ class LegacyEnergySetup(EnergySetup):
         self.energy_calibration = {k: d[k] for k in ("detection_threshold", "param_dist_remap_coefs",
                                                      "param_dist_remap_intercepts", "min_area", "max_area")}
 
+    def calibrate(self, image_configs, rng, save_path: str = None):
+        """``energy_setup_legacy.py:88-123`` (the alignment histogram there is a figure only)"""
+        from . import calibration as C
+        from .shapes import Rectangle
+        thr = C.calibrate_detection_threshold([c.detection_map for c in image_configs], [c.labels for c in image_configs],
+                                              target=self.calibration_params.get("threshold_target"))
+        coefs, intercepts = C.calibrate_param_dists([c.param_dist_maps for c in image_configs],
+                                                    [c.gt_config for c in image_configs], image_configs[0].mappings,
+                                                    Rectangle.PARAMETERS, rng)
+        min_area, max_area = C.calibrate_min_area([c.gt_config for c in image_configs])
+        self.energy_calibration = {"detection_threshold": thr, "param_dist_remap_coefs": coefs,
+                                   "param_dist_remap_intercepts": intercepts, "min_area": min_area, "max_area": max_area}
+        if save_path:
+            with open(os.path.join(save_path, "calibration.json"), "w") as f:
+                json.dump(self.energy_calibration, f, indent=1)
+
     @property
     def detection_threshold(self):
         return float(self.energy_calibration["detection_threshold"])
@@ -266,6 +282,22 @@ class NoCalibrationEnergySetup(EnergySetup):
         self.energy_calibration = {"min_area": d["min_area"], "max_area": d["max_area"],
                                    "param_dist_remap_coefs": d.get("param_dist_remap_coefs"),
                                    "param_dist_remap_intercepts": d.get("param_dist_remap_intercepts")}
+
+    def calibrate(self, image_configs, rng, save_path: str = None):
+        """``energy_setup_no_calibration.py:112-144``"""
+        from . import calibration as C
+        from .shapes import Rectangle
+        min_area, max_area = C.calibrate_min_area([c.gt_config for c in image_configs])
+        coefs, intercepts = None, None
+        if self.calib_marks:
+            coefs, intercepts = C.calibrate_param_dists([c.param_dist_maps for c in image_configs],
+                                                        [c.gt_config for c in image_configs], image_configs[0].mappings,
+                                                        Rectangle.PARAMETERS, rng)
+        self.energy_calibration = {"min_area": min_area, "max_area": max_area, "param_dist_remap_coefs": coefs,
+                                   "param_dist_remap_intercepts": intercepts}
+        if save_path:
+            with open(os.path.join(save_path, "calibration.json"), "w") as f:
+                json.dump({"detection_threshold": None, **self.energy_calibration}, f, indent=1)
 
     @property
     def detection_threshold(self):

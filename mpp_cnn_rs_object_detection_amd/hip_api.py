@@ -24,7 +24,7 @@ MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 8
 ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
-    "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
+    "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
@@ -98,6 +98,7 @@ def load_library(path: Optional[str] = None):
         "mpp_count": (i32, [vp, i32, C.POINTER(C.c_int32)]),
         "mpp_total_energy": (i32, [vp, i32, C.POINTER(dbl), vp]),
         "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
         "mpp_papangelou": (i32, [vp, i32, vp]),
         "mpp_naive_init": (i32, [vp, dbl, dbl]),
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
@@ -293,7 +294,8 @@ class MppContext:
         self._check(self._L.mpp_total_energy(self._h, tile, C.byref(e), _ptr(vec)))
         return (e.value, vec) if return_vectors else e.value
 
-    def delta_batch(self, tile: int, removals: Sequence[Sequence[int]], add_xy: Sequence, add_marks: Sequence):
+    @staticmethod
+    def _pack_cases(removals, add_xy, add_marks):
         n = len(removals)
         rem_off = np.zeros(n + 1, np.int32)
         add_off = np.zeros(n + 1, np.int32)
@@ -309,10 +311,27 @@ class MppContext:
             rem = np.zeros(1, np.int32)
         if len(axy) == 0:
             axy, am = np.zeros((1, 2), np.int32), np.zeros((1, 3))
+        return n, rem_off, rem, add_off, axy, am
+
+    def delta_batch(self, tile: int, removals: Sequence[Sequence[int]], add_xy: Sequence, add_marks: Sequence):
+        n, rem_off, rem, add_off, axy, am = self._pack_cases(removals, add_xy, add_marks)
         out = np.zeros(n, np.float64)
         self._check(self._L.mpp_delta_batch(self._h, tile, n, _ptr(rem_off), _ptr(rem), _ptr(add_off), _ptr(axy),
                                             _ptr(am), _ptr(out)))
         return out
+
+    def delta_vectors(self, tile: int, removals: Sequence[Sequence[int]], add_xy: Sequence, add_marks: Sequence,
+                      n_terms: int):
+        """before, after [n_cases][stride][n_terms] and mask [n_cases][stride] (see mpp_delta_vectors)"""
+        n, rem_off, rem, add_off, axy, am = self._pack_cases(removals, add_xy, add_marks)
+        stride = self.count(tile) + (int(np.max(np.diff(add_off))) if n else 0)
+        stride = max(stride, 1)
+        before = np.zeros((n, stride, n_terms), np.float64)
+        after = np.zeros((n, stride, n_terms), np.float64)
+        mask = np.zeros((n, stride), np.uint8)
+        self._check(self._L.mpp_delta_vectors(self._h, tile, n, _ptr(rem_off), _ptr(rem), _ptr(add_off), _ptr(axy),
+                                              _ptr(am), stride, _ptr(before), _ptr(after), _ptr(mask)))
+        return before, after, mask
 
     def papangelou(self, tile: int = 0) -> np.ndarray:
         out = np.zeros(max(self.count(tile), 1), np.float64)

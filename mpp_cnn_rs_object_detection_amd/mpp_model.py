@@ -34,6 +34,25 @@ from .shapes import Rectangle, rect_to_poly, sra_to_wla
 TRAIN_MODES = ["manual", "grad_descent", "integral_criterion", "ordering_criterion"]
 
 
+def save_energy_combinator(model, save_path: str):
+    """the JSON twin of the reference's ``energy_combination_model.pkl`` (mpp_model.py:199-200)"""
+    if isinstance(model, E.LogisticEnergyCombinator):
+        d = {"type": "LogisticEnergyCombinator", "weights": np.asarray(model.weights, dtype=float).tolist(),
+             "bias": float(model.bias), "energy_names": list(model.energy_names)}
+    elif isinstance(model, E.HierarchicalEnergyCombinator):
+        d = {"type": "HierarchicalEnergyCombinator", "weights_data": np.asarray(model.weights_data, float).tolist(),
+             "weights_prior": np.asarray(model.weights_prior, float).tolist(),
+             "data_prior_weights": np.asarray(model.data_prior_weights, float).tolist(),
+             "detection_threshold": float(model.detection_threshold), "bias": float(model.bias)}
+    elif isinstance(model, E.ManualHierarchicalEnergyCombinator):
+        d = {"type": "ManualHierarchicalEnergyCombinator", "weights_dict": model.weights_dict,
+             "indicator_energy": model.indicator_energy, "detection_threshold": model.detection_threshold}
+    else:
+        raise TypeError(type(model))
+    with open(os.path.join(save_path, "energy_combination_model.json"), "w") as f:
+        json.dump(d, f, indent=1)
+
+
 def load_energy_combinator(save_path: str):
     """``energy_combination_model.json`` (this build) or, for models stored by the reference, its pickle
     -- read with a restricted unpickler that only rebuilds the two combinator classes and numpy arrays."""
@@ -110,8 +129,23 @@ class MPPModel:
                 else:
                     raise
         else:
-            raise NotImplementedError("calibration / weight learning are outside this build: start from a stored "
-                                      "model (calibration.json + energy_combination_model.json)")
+            assert phase == "train"
+            self.__init_data__("train")
+            self.calibrate()
+
+    def __init_data__(self, subset: str):
+        """``mpp_model.py:96-104``: random training patches, ``batch_size`` of them per step"""
+        from .data_loaders import MPPDataset
+        ds = self.config["dataset"]
+        self.data = MPPDataset(dataset=ds["dataset"], subset=subset, position_model=ds["position_model"],
+                               shape_model=ds["shape_model"], patch_size=ds.get("patch_size", PATCH_SIZE), nets=self.nets)
+        self.batch_size = int(self.config.get("data_loader", {}).get("batch_size", 8))
+
+    def calibrate(self):
+        """``mpp_model.py:106-122``"""
+        n = min(int(self.config["calibration"]["n_images"]), len(self.data))
+        idx = self.rng.choice(range(len(self.data)), size=n, replace=False)
+        self.energy_setup.calibrate(image_configs=[self.data[i] for i in idx], rng=self.rng, save_path=self.save_path)
 
     def _find_train_mode(self):
         modes = [t for t in TRAIN_MODES if t in self.config]
@@ -122,8 +156,22 @@ class MPPModel:
 
     def train(self):
         mode = self._find_train_mode()
+        if mode == "ordering_criterion":
+            from .train_ordering_criterion import Logger, train_ordering_criterion
+
+            class _Loader:                        # a fresh epoch of random patches each time it is iterated
+                def __init__(s, data, bs): s.data, s.bs = data, bs
+                def __len__(s): return (len(s.data) + s.bs - 1) // s.bs
+                def __iter__(s): return iter(s.data.batches(s.bs))
+            self.energy_model = train_ordering_criterion(
+                train_loader=_Loader(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
+                logger=Logger(self.save_path), energy_setup=self.energy_setup, device=self.device,
+                **self.config["ordering_criterion"])
+            save_energy_combinator(self.energy_model, self.save_path)
+            return
         if mode != "manual":
-            raise NotImplementedError(f"train mode {mode!r}: only 'manual' is built (reference mpp_model.py:155-183)")
+            raise NotImplementedError(f"train mode {mode!r}: 'manual' and 'ordering_criterion' are built "
+                                      f"(reference mpp_model.py:137-197)")
         m = self.config["manual"]
         if isinstance(self.energy_setup, E.LegacyEnergySetup):
             self.energy_model = E.hierarchical_from_manual(m)

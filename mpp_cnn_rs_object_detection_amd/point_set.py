@@ -179,6 +179,19 @@ class EPointsSet:
         enc = [self._encode(p) for p in perturbations]
         return self._ctx.delta_batch(0, [e[0] for e in enc], [e[1] for e in enc], [e[2] for e in enc])
 
+    def energy_delta_vectors(self, perturbations: Sequence[Perturbation], names: Optional[Sequence[str]] = None):
+        """Energy vectors of the points each perturbation touches, before and after it (``mpp_delta_vectors``):
+        before, after [n][stride][n_terms], mask [n][stride] -- the input of a differentiable combinator.
+        ``names`` orders the columns (``energy_setup.energy_names``); default: unit terms, then pair terms."""
+        self._use(None)
+        enc = [self._encode(p) for p in perturbations]
+        before, after, mask = self._ctx.delta_vectors(0, [e[0] for e in enc], [e[1] for e in enc], [e[2] for e in enc],
+                                                      len(self._ctx.names))
+        if names is not None:
+            cols = [self._ctx.names.index(n) for n in names]
+            before, after = before[..., cols], after[..., cols]
+        return before, after, mask
+
     def papangelou(self, u: Point, energy_combinator=None, remove_u_from_point_set: bool = False,
                    return_energy_delta: bool = False):
         """Reference ``energy_point_set.py:102-116``."""

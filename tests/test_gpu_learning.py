@@ -1,0 +1,140 @@
+"""Weight learning: ``mpp_delta_vectors`` against the oracle's from-scratch energy vectors, the
+criterion against a plain torch evaluation of the reference's formula on oracle vectors, and a short training run
+that must separate the ground truth from its perturbations (train_ordering_criterion.py:43-219)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import hrc_model, log_model
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import mappings, synth
+from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps
+from mpp_cnn_rs_object_detection_amd.shapes import Rectangle
+
+pytestmark = pytest.mark.gpu
+
+
+def image_data(tile, name="0000"):
+    gt = [Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2]))
+          for (x, y), m in zip(tile.gt_xy, tile.gt_marks)]
+    return ImageWMaps(name=name, shape=tile.shape, image=None, detection_map=tile.det, param_dist_maps=tile.marks,
+                      mappings=mappings.default_mappings(), param_names=Rectangle.PARAMETERS, gt_config=gt)
+
+
+def rows_of(points):
+    return (np.array([[p.x, p.y] for p in points], np.int32).reshape(-1, 2),
+            np.array([[p.size, p.ratio, p.angle] for p in points], np.float64).reshape(-1, 3))
+
+
+def setup_case(model_fn, tile_id=31, size=128, n=30, n_samples=10):
+    from mpp_cnn_rs_object_detection_amd.perturbation_sampler import sample_multiple_kernel_perturbations
+    from mpp_cnn_rs_object_detection_amd.point_set import EPointsSet
+    tile = synth.make_tile(size, n, tile_id=tile_id, noise=0.2)
+    data = image_data(tile)
+    setup, comb = model_fn()
+    unit, pair = setup.make_energies(data)
+    base = EPointsSet(data.gt_config, data.shape, unit, pair, image_data=data)
+    data.gt_config_set = base
+    perts = sample_multiple_kernel_perturbations(data, n_samples=n_samples, rng=np.random.default_rng(3), energy_setup=setup,
+                                                 iter_per_point=1.0, return_perturbations=True, aggregate_pert=True)
+    return tile, data, setup, comb, unit, pair, base, perts
+
+
+@pytest.mark.parametrize("model_fn", [hrc_model, log_model])
+def test_delta_vectors_equal_the_oracle_vectors(model_fn):
+    tile, data, setup, comb, unit, pair, base, perts = setup_case(model_fn)
+    before, after, mask = base.energy_delta_vectors(perts)
+    n = len(data.gt_config)
+    assert before.shape[:2] == mask.shape and before.shape[2] == len(setup.energy_names)
+    o = oracle.Oracle(tile.shape, tile.det, tile.marks, E.build_model_desc(unit, pair, None))
+    o.set_points(*rows_of(data.gt_config))
+    _, v0 = o.total_energy(return_vectors=True)
+    index = {p: i for i, p in enumerate(data.gt_config)}
+    seen = set()
+    for k, p in enumerate(perts):
+        removed = [index[r] for r in p.removal]
+        kept = [i for i in range(n) if i not in removed]
+        new = [data.gt_config[i] for i in kept] + list(p.addition)
+        o.set_points(*rows_of(new))
+        _, v1 = o.total_energy(return_vectors=True)
+        m = mask[k]
+        assert sorted(np.where(m == 2)[0]) == sorted(removed)
+        assert list(np.where(m == 3)[0]) == list(range(n, n + len(p.addition)))
+        for i in range(n):
+            if m[i] == 2:
+                np.testing.assert_allclose(before[k, i], v0[i], rtol=1e-9, atol=1e-9)
+            else:
+                j = kept.index(i)
+                if m[i] == 1:
+                    np.testing.assert_allclose(before[k, i], v0[i], rtol=1e-9, atol=1e-9)
+                    np.testing.assert_allclose(after[k, i], v1[j], rtol=1e-9, atol=1e-9)
+                else:                                         # untouched: its vector did not change
+                    np.testing.assert_allclose(v1[j], v0[i], rtol=1e-12, atol=1e-12)
+            seen.add(int(m[i]))
+        for a in range(len(p.addition)):
+            np.testing.assert_allclose(after[k, n + a], v1[len(kept) + a], rtol=1e-9, atol=1e-9)
+    assert seen == {0, 1, 2}
+    with pytest.raises(KeyError):
+        from mpp_cnn_rs_object_detection_amd.custom_types import Perturbation
+        base.energy_delta_vectors([Perturbation(type=None, removal=Rectangle(1, 1, 5.0, 0.5, 0.1))])
+
+
+@pytest.mark.parametrize("model_fn,kind", [(hrc_model, "hierarchical"), (log_model, "logistic")])
+def test_criterion_equals_the_reference_formula_on_oracle_vectors(model_fn, kind):
+    """loss = -mean_k [forward(V_after_subset) - forward(V_before_subset)], and with a NumPy combinator of the same
+    weights the deltas are the ones of energy_delta_batch"""
+    from mpp_cnn_rs_object_detection_amd.train_ordering_criterion import criterion_loss, perturbation_rows
+    from mpp_cnn_rs_object_detection_amd.weight_models import init_model
+    tile, data, setup, comb, unit, pair, base, perts = setup_case(model_fn, tile_id=32)
+    torch.manual_seed(0)
+    wm = init_model(kind, setup)
+    with torch.no_grad():
+        for p_ in wm.parameters():
+            p_.add_(0.3 * torch.randn_like(p_))
+    rows, sign, case = perturbation_rows(base, perts, names=setup.energy_names)
+    loss = criterion_loss(wm, [(rows, sign, case, len(perts))])
+    # the same with whole configurations, the slow way: E(config) = forward(all vectors)
+    desc = E.build_model_desc(unit, pair, None)
+    o = oracle.Oracle(tile.shape, tile.det, tile.marks, desc)
+    cols = [list(desc.names).index(nm) for nm in setup.energy_names]     # oracle columns: unit terms, then pair terms
+    assert cols != list(range(len(cols)))                                 # the two orders really differ
+    n = len(data.gt_config)
+    index = {p: i for i, p in enumerate(data.gt_config)}
+    o.set_points(*rows_of(data.gt_config))
+    _, v0 = o.total_energy(return_vectors=True)
+    e0 = wm.forward(torch.tensor(v0[:, cols], dtype=torch.float64))
+    deltas = []
+    for p in perts:
+        removed = {index[r] for r in p.removal}
+        new = [data.gt_config[i] for i in range(n) if i not in removed] + list(p.addition)
+        o.set_points(*rows_of(new))
+        _, v1 = o.total_energy(return_vectors=True)
+        deltas.append(wm.forward(torch.tensor(v1[:, cols], dtype=torch.float64)) - e0)
+    ref = -torch.mean(torch.stack(deltas))
+    assert float(loss.detach()) == pytest.approx(float(ref.detach()), rel=2e-4, abs=2e-4)        # float32 rows vs float64 whole sums
+    loss.backward()
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in wm.parameters())
+    # the trained model's NumPy twin drives the sampler's own delta: same numbers
+    comb2 = wm.get_energy_combination_function()
+    d_gpu = base.energy_delta_batch(perts, comb2)
+    np.testing.assert_allclose(d_gpu, [float(d.detach()) for d in deltas], rtol=2e-5, atol=2e-5)
+
+
+def test_training_lowers_the_loss_and_orders_ground_truth_first(tmp_path):
+    from mpp_cnn_rs_object_detection_amd.train_ordering_criterion import Logger, train_ordering_criterion
+    setup, _ = log_model()
+    tiles = [image_data(synth.make_tile(128, 30, tile_id=40 + k, noise=0.2), name=f"{k:04}") for k in range(4)]
+    loader = [tiles[:2], tiles[2:]]
+    logger = Logger(str(tmp_path))
+    comb = train_ordering_criterion(loader, np.random.default_rng(0), logger, samples_per_image=8, n_epochs=6,
+                                    save_dir=str(tmp_path), energy_setup=setup, optim="adam", learning_rate=0.05,
+                                    weight_model_type="logistic", neg_pert_config={"iter_per_point": 1.0},
+                                    lr_scheduler=True, lr_scheduler_params={"gamma": 0.95})
+    loss = logger.log["loss"]
+    assert len(loss) == 12 and np.mean(loss[-4:]) < np.mean(loss[:4]) - 0.5
+    assert set(logger.log) >= {"epoch", "timestamp", "batch", "loss", "lr", "PositionEnergy_weight", "bias"}
+    # held-out tile: the ground truth has a lower energy than every perturbation of it
+    tile, data, _, _, unit, pair, base, perts = setup_case(log_model, tile_id=77, n_samples=16)
+    d = base.energy_delta_batch(perts, comb)
+    assert (d > 0).mean() >= 0.9

@@ -127,33 +127,40 @@ def synthetic_dataset(tmp_path):
         shutil.copytree(os.path.join(REPO, d), root / d)
     with open(root / "paths_config.json", "w") as f:
         json.dump({"dataset_path": ["data/"], "model_path": ["models_storage/"]}, f)
-    H, W = 300, 420                       # not a multiple of 256: overlapping tiles + merge
-    gt_xy, gt_marks = synth.make_gt(300, 70, tile_id=21)
-    extra_xy, extra_marks = synth.make_gt(300, 20, tile_id=22)
+    gt_xy = write_image(root, "val", 7, 21)
+    return root, gt_xy
+
+
+def write_image(root, subset, image_id, seed):
+    """one 300 x 420 image (not a multiple of 256: overlapping tiles + merge) with its score-map pickles"""
+    H, W = 300, 420
+    gt_xy, gt_marks = synth.make_gt(300, 70, tile_id=seed)
+    extra_xy, extra_marks = synth.make_gt(300, 20, tile_id=seed + 1)
     sel = extra_xy[:, 1] < 110
     gt_xy = np.concatenate([gt_xy, extra_xy[sel] + np.array([0, 300])])
     gt_marks = np.concatenate([gt_marks, extra_marks[sel]])
     det, marks = synth.render_maps((H, W), gt_xy, gt_marks)
     from matplotlib import pyplot as plt
-    base = root / "data" / "SYNTH" / "val"
+    base = root / "data" / "SYNTH" / subset
     for sub in ("images", "annotations", "metadata"):
-        os.makedirs(base / sub)
-    plt.imsave(base / "images" / "0007.png", np.stack([det] * 3, axis=-1))
+        os.makedirs(base / sub, exist_ok=True)
+    plt.imsave(base / "images" / f"{image_id:04}.png", np.stack([det] * 3, axis=-1))
     b = 2 * gt_marks[:, 0] / (1 + gt_marks[:, 1])
     params = np.stack([b * gt_marks[:, 1], b, gt_marks[:, 2]], axis=1)      # (a, b, angle)
-    with open(base / "annotations" / "0007.pkl", "wb") as f:
+    with open(base / "annotations" / f"{image_id:04}.pkl", "wb") as f:
         pickle.dump({"centers": gt_xy.astype(np.int64), "parameters": params,
                      "categories": np.array(["small-vehicle"] * len(gt_xy), dtype=object),
                      "difficult": np.zeros(len(gt_xy), dtype=np.int64)}, f)
-    with open(base / "metadata" / "0007.json", "w") as f:
-        json.dump({}, f)
+    with open(base / "metadata" / f"{image_id:04}.json", "w") as f:
+        json.dump({"shape": [H, W], "n_objects": int(len(gt_xy))}, f)
     for model, payload in (("posvec_dota", {"detection_map": det}),
                            ("shape_dota", {"output": [np.moveaxis(m, -1, 0)[None] for m in marks],
                                            "mappings": mappings.default_mappings()})):
-        d = root / "data" / "inference" / "SYNTH" / "val" / model
-        os.makedirs(d)
-        with open(d / "0007_results.pkl", "wb") as f:
+        d = root / "data" / "inference" / "SYNTH" / subset / model
+        os.makedirs(d, exist_ok=True)
+        with open(d / f"{image_id:04}_results.pkl", "wb") as f:
             pickle.dump(payload, f)
+    return gt_xy
     return root, gt_xy
 
 
@@ -185,3 +192,37 @@ def test_main_infer_mpp_end_to_end(synthetic_dataset, config):
             m = json.load(f)["vehicle"]
         assert m["ap"] > 0.9 and len(m["precision"]) == len(m["recall"]) == len(centers)
         assert os.path.exists(out / ("dota" + postfix) / "metrics0.75.json")
+
+
+def test_main_train_then_infereval_with_the_learned_weights(synthetic_dataset):
+    """``main.py -p train -m mpp -c config_mpp_log.json``: calibration + ordering-criterion weight learning on random
+    training patches (mpp_model.py:106-200), then inference + evaluation with what was learned."""
+    root, gt_xy = synthetic_dataset
+    for k, seed in enumerate((31, 41, 51)):
+        write_image(root, "train", k, seed)
+    store = root / "models_storage" / "mpp" / "mpp_log"
+    for f in ("calibration.json", "energy_combination_model.json"):
+        os.remove(store / f)                                   # they must come from this run
+    cfg = json.load(open(root / "model_configs" / "mpp" / "config_mpp_log.json"))
+    cfg["ordering_criterion"].update(n_epochs=6, samples_per_image=8)
+    cfg["data_loader"]["batch_size"] = 3
+    cfg["inference"]["rjmcmc_params"]["burn_in"] = 12000
+    with open(root / "cfg_train.json", "w") as f:
+        json.dump(cfg, f)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    run = lambda proc: subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", proc, "-m", "mpp", "-c",
+                                       str(root / "cfg_train.json"), "-d", "SYNTH", "-o"], cwd=root, env=env,
+                                      capture_output=True, text=True, timeout=900)
+    r = run("train")
+    assert r.returncode == 0, r.stderr[-3000:]
+    cal = json.load(open(store / "calibration.json"))
+    assert 20 < cal["min_area"] < cal["max_area"] < 80          # objects are ~4.5 x 9 px
+    comb = json.load(open(store / "energy_combination_model.json"))
+    assert comb["type"] == "LogisticEnergyCombinator" and len(comb["weights"]) == 8
+    log = json.load(open(store / "log.json"))
+    assert len(log["loss"]) == 6 and log["loss"][-1] < log["loss"][0] and "PositionEnergy_weight" in log
+    r = run("infereval")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = root / "data" / "inference" / "SYNTH" / "val" / "mpp_log"
+    with open(out / "dota" / "metrics0.25.json") as f:
+        assert json.load(f)["vehicle"]["ap"] > 0.85
