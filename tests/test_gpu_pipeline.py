@@ -226,3 +226,33 @@ def test_main_train_then_infereval_with_the_learned_weights(synthetic_dataset):
     out = root / "data" / "inference" / "SYNTH" / "val" / "mpp_log"
     with open(out / "dota" / "metrics0.25.json") as f:
         assert json.load(f)["vehicle"]["ap"] > 0.85
+
+
+def test_borrowed_device_maps_give_the_same_chain_as_uploaded_host_maps():
+    """The U-Net epilogues leave the score maps in HBM and the sampler borrows them (``mpp_set_maps(on_device=1)``,
+    SURVEY 8(b) "score-map hand-off stays on device"): same detections as with host arrays, tile by tile."""
+    import torch
+    from mpp_cnn_rs_object_detection_amd.mpp_model import MPPModel
+    cfg = json.load(open(os.path.join(REPO, "model_configs", "mpp", "mpp_hrcM.json")))
+    cfg["inference"]["rjmcmc_params"]["burn_in"] = 4000
+    cwd = os.getcwd()
+    os.chdir(REPO)
+    try:
+        model = MPPModel(cfg, phase="val", load=True)
+    finally:
+        os.chdir(cwd)
+    gt_xy, gt_marks = synth.make_gt(300, 60, tile_id=61)
+    det, marks = synth.render_maps((300, 400), gt_xy, gt_marks)
+    host = ImageWMaps(name="0001", shape=(300, 400), image=None, detection_map=det, param_dist_maps=marks,
+                      mappings=mappings.default_mappings(), param_names=Rectangle.PARAMETERS, gt_config=[])
+    dev = ImageWMaps(name="0001", shape=(300, 400), image=None, detection_map=torch.from_numpy(det).cuda(),
+                     param_dist_maps=[torch.from_numpy(m).cuda() for m in marks],
+                     mappings=mappings.default_mappings(), param_names=Rectangle.PARAMETERS, gt_config=[])
+    model.rng = np.random.default_rng(0)
+    a, sa = model.infer_image(host)
+    model.rng = np.random.default_rng(0)
+    b, sb = model.infer_image(dev)
+    pa = sorted((p.x, p.y, p.size, p.ratio, p.angle) for p in a)
+    pb = sorted((p.x, p.y, p.size, p.ratio, p.angle) for p in b)
+    assert pa == pb and len(pa) > 5            # (a short, still hot chain: only the equality matters here)
+    np.testing.assert_allclose(sorted(sa), sorted(sb), rtol=1e-12)
