@@ -15,9 +15,9 @@ import numpy as np
 
 from .mappings import ValueMapping
 
-K_UBIRTH, K_UDEATH, K_DBIRTH, K_DDEATH, K_GTRANS, K_DTRANS, K_GTRANSF, K_DTRANSF = range(8)
+K_UBIRTH, K_UDEATH, K_DBIRTH, K_DDEATH, K_GTRANS, K_DTRANS, K_GTRANSF, K_DTRANSF, K_SPLIT, K_MERGE = range(10)
 KERNEL_NAMES = ["UniformBirth", "UniformDeath", "DataBirth", "DataDeath", "GaussianTranslation",
-                "DataDrivenTranslation", "GaussianShapeTransform", "DataDrivenShapeTransform"]
+                "DataDrivenTranslation", "GaussianShapeTransform", "DataDrivenShapeTransform", "Split", "Merge"]
 
 BASE_KERNEL_WEIGHTS = {
     "bd_weight": 1, "uniform_bd_weight": 1, "data_bd_weight": 2, "ms_weight": 1,
@@ -28,7 +28,7 @@ BASE_KERNEL_WEIGHTS = {
 
 @dataclass
 class KernelDesc:
-    p_kernel: np.ndarray                  # [8]
+    p_kernel: np.ndarray                  # [10]; the last two (split, merge) are 0 unless use_split_merge
     intensity: float
     vmin: np.ndarray                      # [3]
     vmax: np.ndarray
@@ -37,6 +37,8 @@ class KernelDesc:
     sigma_trans: float = 2.0              # make_kernels.py:118
     sigma_transform: float = 0.1          # make_kernels.py:130
     max_delta: int = 8                    # make_kernels.py:124
+    split_radius: float = 16.0            # make_kernels.py:148
+    split_sigma: float = 0.1              # make_kernels.py:150
 
 
 def _l1(v: Sequence[float]) -> np.ndarray:
@@ -46,16 +48,17 @@ def _l1(v: Sequence[float]) -> np.ndarray:
 
 def make_kernels(mappings: List[ValueMapping], intensity: float, use_split_merge: bool = False,
                  kernel_weights: Dict[str, float] = None) -> KernelDesc:
-    if use_split_merge:
-        raise NotImplementedError("split/merge kernels (reference split_and_merge_kernels.py) are not built; "
-                                  "both shipped configs run without them")
     w = kernel_weights or BASE_KERNEL_WEIGHTS
-    p_bd, p_trl, p_trf = _l1([w["bd_weight"], w["translation_weight"], w["transformation_weight"]])
+    if use_split_merge:                   # make_kernels.py:75-77
+        p_bd, p_ms, p_trl, p_trf = _l1([w["bd_weight"], w["ms_weight"], w["translation_weight"], w["transformation_weight"]])
+    else:
+        p_bd, p_trl, p_trf = _l1([w["bd_weight"], w["translation_weight"], w["transformation_weight"]])
+        p_ms = 0.0
     p_bd_unif, p_bd_data = _l1([w["uniform_bd_weight"], w["data_bd_weight"]])
     p_trl_g, p_trl_d = _l1([w["gaussian_translation_weight"], w["data_translation_weight"]])
     p_trf_g, p_trf_d = _l1([w["gaussian_transformation_weight"], w["data_transformation_weight"]])
     p = np.array([0.5 * p_bd_unif * p_bd, 0.5 * p_bd_unif * p_bd, 0.5 * p_bd_data * p_bd, 0.5 * p_bd_data * p_bd,
-                  p_trl * p_trl_g, p_trl * p_trl_d, p_trf * p_trf_g, p_trf * p_trf_d])
+                  p_trl * p_trl_g, p_trl * p_trl_d, p_trf * p_trf_g, p_trf * p_trf_d, p_ms * 0.5, p_ms * 0.5])
     if abs(1 - p.sum()) < 1e-8:
         p = p / p.sum()
     if len(mappings) != 3 or any(m.n_classes != 32 for m in mappings):

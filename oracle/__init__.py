@@ -23,7 +23,7 @@ _BUILD = os.path.join(_HERE, "_build")
 _LIB_PATH = os.path.join(_BUILD, "liboracle.so")
 _SRC = [os.path.join(_HERE, "mpp_oracle.c"), os.path.join(_HERE, "mpp_oracle.h")]
 
-MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 8
+MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 
 
 class UnitTerm(C.Structure):
@@ -44,7 +44,8 @@ class Model(C.Structure):
 class Kernels(C.Structure):
     _fields_ = [("p_kernel", C.c_double * NKERNEL), ("intensity", C.c_double), ("sigma_trans", C.c_double),
                 ("sigma_transform", C.c_double), ("max_delta", C.c_int32), ("cyclic", C.c_int32 * 3),
-                ("vmin", C.c_double * 3), ("vmax", C.c_double * 3), ("edges", (C.c_double * NCLASS) * 3)]
+                ("vmin", C.c_double * 3), ("vmax", C.c_double * 3), ("edges", (C.c_double * NCLASS) * 3),
+                ("split_radius", C.c_double), ("split_sigma", C.c_double)]
 
 
 class Proposal(C.Structure):
@@ -139,7 +140,8 @@ def _kernel_struct(kd) -> Kernels:
                 k.edges[j][i] = float(e[i])
         return k
     for i in range(NKERNEL):
-        k.p_kernel[i] = float(kd.p_kernel[i])
+        k.p_kernel[i] = float(kd.p_kernel[i]) if i < len(kd.p_kernel) else 0.0
+    k.split_radius, k.split_sigma = float(getattr(kd, "split_radius", 16.0)), float(getattr(kd, "split_sigma", 0.1))
     k.intensity, k.sigma_trans, k.sigma_transform, k.max_delta = kd.intensity, kd.sigma_trans, kd.sigma_transform, \
         kd.max_delta
     for j in range(3):

@@ -25,6 +25,7 @@
 #define AREA_EPS 1e-6            /* prior_energies.py:18 */
 #define DEGENERATE_AREA 1e-12    /* zero-width rectangle: intersection area is 0 */
 #define TWO_PI 6.283185307179586476925286766559
+#define PI_ 3.14159265358979323846264338327950288
 
 typedef struct { int32_t x, y; double s, r, a; } rect_t;
 
@@ -34,6 +35,7 @@ struct orc_ctx {
   orc_model model;
   orc_kernels kern;
   double p_cum[ORC_NKERNEL];
+  int n_active;              /* 8, or 10 with the split / merge kernels */
   double res;                 /* spatial resolution, point_set.py:58 */
   int nx, ny, max_offset;
   double max_inter;           /* energy_graph.py:26-29 */
@@ -351,6 +353,7 @@ orc_ctx *orc_create(int H, int W, const float *det, const float *m0, const float
   if (kernels) c->kern = *kernels;
   double acc = 0.0;
   for (int k = 0; k < ORC_NKERNEL; ++k) { acc += c->kern.p_kernel[k]; c->p_cum[k] = acc; }
+  c->n_active = (c->kern.p_kernel[ORC_K_SPLIT] > 0.0 || c->kern.p_kernel[ORC_K_MERGE] > 0.0) ? ORC_NKERNEL : ORC_K_SPLIT;
   double maxd = 0.0;
   for (int p = 0; p < model->n_pair; ++p) if (model->pair[p].max_dist > maxd) maxd = model->pair[p].max_dist;
   /* energy_point_set.py:33-36, point_set.py:58-61, energy_graph.py:26-29 */
@@ -537,12 +540,84 @@ static double wrap_mark(const orc_ctx *c, int k, double v) {
 }
 static inline void set_mark(rect_t *q, int k, double v) { if (k == 0) q->s = v; else if (k == 1) q->r = v; else q->a = v; }
 
-/* draw the proposal of step `step` from its 12 random words */
-static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *pr) {
+/* ValueMapping.clip (shape_net/mappings.py:52-58): modulo for cyclic marks, clamp otherwise */
+static double clip_mark(const orc_ctx *c, int k, double v) {
+  double lo = c->kern.vmin[k], hi = c->kern.vmax[k];
+  if (c->kern.cyclic[k]) {
+    double range = hi - lo, m = fmod(v - lo, range);
+    if (m < 0) m += range;
+    return m + lo;
+  }
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+static inline int clip_int(double v, int hi) { return (int)(v < 0.0 ? 0.0 : (v > (double)hi ? (double)hi : v)); }
+/* the two rectangles of a split (split_and_merge_kernels.py:56-73) */
+static void split_rects(const orc_ctx *c, const rect_t *p, const orc_proposal *pr, rect_t *a0, rect_t *a1) {
+  const double sd[3] = {pr->as, pr->ar, pr->aa};
+  a0->x = clip_int((double)p->x - pr->aux0, c->H - 1); a0->y = clip_int((double)p->y - pr->aux1, c->W - 1);
+  a1->x = clip_int((double)p->x + pr->aux0, c->H - 1); a1->y = clip_int((double)p->y + pr->aux1, c->W - 1);
+  for (int k = 0; k < 3; ++k) {
+    set_mark(a0, k, clip_mark(c, k, mark_of(p, k) - sd[k]));
+    set_mark(a1, k, clip_mark(c, k, mark_of(p, k) + sd[k]));
+  }
+}
+/* the rectangle two points merge into (split_and_merge_kernels.py:128-135; the column is clipped with
+ * shape[0] upstream, reproduced) */
+static void merge_rect(const orc_ctx *c, const rect_t *p0, const rect_t *p1, rect_t *q) {
+  q->x = clip_int(((double)p0->x + (double)p1->x) / 2.0, c->H - 1);
+  q->y = clip_int(((double)p0->y + (double)p1->y) / 2.0, c->H - 1);
+  for (int k = 0; k < 3; ++k) set_mark(q, k, clip_mark(c, k, (mark_of(p0, k) + mark_of(p1, k)) / 2.0));
+}
+/* SplitSampler.pdf (split_and_merge_kernels.py:33-36) */
+static double split_pdf(const orc_ctx *c, const double sd[3]) {
+  double R = c->kern.split_radius, p = 1.0 / (PI_ * R * R);
+  for (int k = 0; k < 3; ++k) p *= normal_pdf(sd[k], c->kern.split_sigma * (c->kern.vmax[k] - c->kern.vmin[k]));
+  return p;
+}
+/* len(get_potential_neighbors(u, radius)): every point of the (2*ceil(r/res)+1)^2 cells (point_set.py:111-145) */
+static int count_potential(const orc_ctx *c, int x, int y, double radius) {
+  int off = (int)ceil(radius / c->res), ci = cell_i(c, x), cj = cell_i(c, y), cnt = 0;
+  for (int di = -off; di <= off; ++di)
+    for (int dj = -off; dj <= off; ++dj) {
+      int i = ci + di, j = cj + dj;
+      if (i < 0 || i >= c->nx || j < 0 || j >= c->ny) continue;
+      cnt += c->cell_cnt[j + i * c->ny];
+    }
+  return cnt;
+}
+/* get_neighbors(p0, radius) (point_set.py:147-149) in the canonical order of this build: ascending (x, y, marks) */
+static int merge_neighbours(const orc_ctx *c, int i0, int *out) {
+  const rect_t *p0 = &c->pt[i0];
+  double R = c->kern.split_radius;
+  int off = (int)ceil(R / c->res), ci = cell_i(c, p0->x), cj = cell_i(c, p0->y), n = 0;
+  for (int di = -off; di <= off; ++di)
+    for (int dj = -off; dj <= off; ++dj) {
+      int i = ci + di, j = cj + dj;
+      if (i < 0 || i >= c->nx || j < 0 || j >= c->ny) continue;
+      int cell = j + i * c->ny;
+      for (int k = 0; k < c->cell_cnt[cell]; ++k) {
+        int v = c->cell_items[cell][k];
+        if (v == i0) continue;
+        double dx = (double)(c->pt[v].x - p0->x), dy = (double)(c->pt[v].y - p0->y);
+        if (sqrt(dx * dx + dy * dy) <= R) out[n++] = v;
+      }
+    }
+  for (int a = 1; a < n; ++a) {                 /* insertion sort by rect_less */
+    int v = out[a], b = a - 1;
+    while (b >= 0 && rect_less(&c->pt[v], &c->pt[out[b]])) { out[b + 1] = out[b]; --b; }
+    out[b + 1] = v;
+  }
+  return n;
+}
+
+/* draw the proposal of step `step` from its 12 random words (split draws further Philox blocks 3.. of the same
+ * step for its rejection sampling) */
+static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *pr, const uint32_t key[2],
+                          uint64_t step, uint32_t chain) {
   memset(pr, 0, sizeof(*pr));
   double uk = u53(w[0], w[1]);
   int k = 0;
-  while (k < ORC_NKERNEL - 1 && c->p_cum[k] <= uk) ++k;  /* Generator.choice: searchsorted(cdf, u, 'right') */
+  while (k < c->n_active - 1 && c->p_cum[k] <= uk) ++k;  /* Generator.choice: searchsorted(cdf, u, 'right') */
   pr->kernel = k; pr->target = -1; pr->param_id = -1; pr->new_class = -1;
   pr->aux0 = pr->aux1 = 0.0;
   pr->u_accept = u53(w[10], w[11]);
@@ -566,10 +641,34 @@ static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *
     return;
   }
   if (n == 0) return;                     /* nothing to remove / move: empty perturbation */
+  if (k == ORC_K_MERGE && n < 2) return;  /* split_and_merge_kernels.py:121 */
   int t = (int)mulhi(w[2], (uint32_t)n);  /* point_set.py:176-185 (uniform pick) */
   pr->target = t;
   rect_t q = c->pt[t];
   if (k == ORC_K_UDEATH || k == ORC_K_DDEATH) return;
+  if (k == ORC_K_SPLIT) {                 /* split_and_merge_kernels.py:23-31 */
+    double R = c->kern.split_radius, px = 0.0, py = 0.0;
+    for (uint32_t a = 0; a < 16; ++a) {   /* uniform in [0,R)^2 until inside the quarter disc */
+      uint32_t e[4], ctr[4] = {(uint32_t)step, (uint32_t)(step >> 32), 3u + a / 2u, chain};
+      orc_philox(ctr, key, e);
+      px = R * u32d(e[2 * (a & 1u)]); py = R * u32d(e[2 * (a & 1u) + 1]);
+      if (!(sqrt(px * px + py * py) > R)) break;
+    }
+    double z[4];
+    box_muller(w[3], w[4], &z[0], &z[1]); box_muller(w[5], w[6], &z[2], &z[3]);
+    pr->aux0 = px; pr->aux1 = py;
+    pr->as = c->kern.split_sigma * (c->kern.vmax[0] - c->kern.vmin[0]) * z[0];
+    pr->ar = c->kern.split_sigma * (c->kern.vmax[1] - c->kern.vmin[1]) * z[1];
+    pr->aa = c->kern.split_sigma * (c->kern.vmax[2] - c->kern.vmin[2]) * z[2];
+    return;
+  }
+  if (k == ORC_K_MERGE) {                 /* split_and_merge_kernels.py:119-127 */
+    int *nb = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    int cnt = merge_neighbours(c, t, nb);
+    pr->param_id = cnt > 0 ? nb[mulhi(w[3], (uint32_t)cnt)] : -1;
+    free(nb);
+    return;
+  }
   if (k == ORC_K_GTRANS) {                /* transform_kernels.py:24-34 */
     double z0, z1; box_muller(w[3], w[4], &z0, &z1);
     double d0 = c->kern.sigma_trans * z0, d1 = c->kern.sigma_trans * z1;
@@ -611,28 +710,54 @@ static void do_step(orc_ctx *c, const orc_proposal *pr, orc_step_out *out) {
   const orc_kernels *K = &c->kern;
   int k = pr->kernel, n = c->n;
   double pk = K->p_kernel[k], fwd = pk, bwd = pk, dE = 0.0;
-  rect_t add = {pr->ax, pr->ay, pr->as, pr->ar, pr->aa};
-  int has_add = 0, has_rem = 0;
-  int32_t rem = pr->target;
+  rect_t add[2] = {{pr->ax, pr->ay, pr->as, pr->ar, pr->aa}, {0, 0, 0.0, 0.0, 0.0}};
+  int n_add = 0, n_rem = 0;
+  int32_t rem[2] = {pr->target, -1};
   if (k == ORC_K_UBIRTH || k == ORC_K_DBIRTH) {
-    has_add = 1;
-    double dens = k == ORC_K_UBIRTH ? 1.0 : birth_density(c, &add);
+    n_add = 1;
+    double dens = k == ORC_K_UBIRTH ? 1.0 : birth_density(c, &add[0]);
     fwd = K->p_kernel[k] * dens / K->intensity;
     bwd = K->p_kernel[k + 1] / (double)(n + 1);
-  } else if (n > 0 && rem >= 0) {
-    has_rem = 1;
-    const rect_t *old = &c->pt[rem];
+  } else if (k == ORC_K_SPLIT) {          /* split_and_merge_kernels.py:79-106 */
+    bwd = K->p_kernel[ORC_K_MERGE];       /* n == 0: forward p_split, backward p_merge */
+    if (n > 0 && rem[0] >= 0) {
+      n_rem = 1; n_add = 2;
+      const double sd[3] = {pr->as, pr->ar, pr->aa};
+      split_rects(c, &c->pt[rem[0]], pr, &add[0], &add[1]);
+      fwd = pk * ((1.0 / (double)n) * split_pdf(c, sd)) / K->intensity;
+      int nn0 = count_potential(c, add[0].x, add[0].y, K->split_radius) + 1;
+      int nn1 = count_potential(c, add[1].x, add[1].y, K->split_radius) + 1;
+      double nb = (double)(n + 1);
+      bwd = K->p_kernel[ORC_K_MERGE] * ((1.0 / nb) * (1.0 / (double)nn0) + (1.0 / nb) * (1.0 / (double)nn1));
+    }
+  } else if (k == ORC_K_MERGE) {          /* split_and_merge_kernels.py:139-170 */
+    bwd = K->p_kernel[ORC_K_SPLIT];       /* fewer than two points, or p0 without neighbour */
+    if (n > 1 && rem[0] >= 0 && pr->param_id >= 0) {
+      rem[1] = pr->param_id;
+      n_rem = 2; n_add = 1;
+      const rect_t *p0 = &c->pt[rem[0]], *p1 = &c->pt[rem[1]];
+      int *nbuf = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+      int n_nb = merge_neighbours(c, rem[0], nbuf);
+      free(nbuf);
+      merge_rect(c, p0, p1, &add[0]);
+      fwd = pk * ((1.0 / (double)n) * (1.0 / (double)n_nb));
+      const double sd[3] = {(p0->s - p1->s) / 2.0, (p0->r - p1->r) / 2.0, (p0->a - p1->a) / 2.0};
+      bwd = K->p_kernel[ORC_K_SPLIT] * ((1.0 / (double)(n - 1)) * split_pdf(c, sd)) / K->intensity;
+    }
+  } else if (n > 0 && rem[0] >= 0) {
+    n_rem = 1;
+    const rect_t *old = &c->pt[rem[0]];
     if (k == ORC_K_UDEATH || k == ORC_K_DDEATH) {
       double dens = k == ORC_K_UDEATH ? 1.0 : birth_density(c, old);
       fwd = K->p_kernel[k] / (double)n;
       bwd = K->p_kernel[k - 1] * dens / K->intensity;
     } else {
-      has_add = 1;
+      n_add = 1;
       if (k == ORC_K_GTRANS) {
         fwd = bwd = pk * normal_pdf(pr->aux0, K->sigma_trans) * normal_pdf(pr->aux1, K->sigma_trans) / (double)n;
       } else if (k == ORC_K_DTRANS) {
-        fwd = pk * move_density(c, old->x, old->y, add.x, add.y) / (double)n;
-        bwd = pk * move_density(c, add.x, add.y, old->x, old->y) / (double)n;
+        fwd = pk * move_density(c, old->x, old->y, add[0].x, add[0].y) / (double)n;
+        bwd = pk * move_density(c, add[0].x, add[0].y, old->x, old->y) / (double)n;
       } else if (k == ORC_K_GTRANSF) {
         int pid = pr->param_id;
         fwd = bwd = pk * normal_pdf(pr->aux0, K->sigma_transform * (K->vmax[pid] - K->vmin[pid])) / (double)n;
@@ -645,13 +770,18 @@ static void do_step(orc_ctx *c, const orc_proposal *pr, orc_step_out *out) {
       }
     }
   }
-  if (has_add || has_rem) dE = delta_rects(c, has_rem, &rem, has_add, &add);
+  if (n_add || n_rem) dE = delta_rects(c, n_rem, rem, n_add, add);
   double log_alpha = (-dE / c->T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN);
   int accepted = log(pr->u_accept + EPS_GREEN) < log_alpha;
   if (accepted) {
-    if (has_rem && has_add) state_update(c, rem, &add);
-    else if (has_rem) state_remove(c, rem);
-    else if (has_add) state_add(c, &add);
+    /* canonical slots: the (first) added point takes the (first) removed point's slot, a second added point is
+     * appended, a second removed point is swap-removed */
+    if (n_rem && n_add) {
+      state_update(c, rem[0], &add[0]);
+      if (n_add == 2) state_add(c, &add[1]);
+      if (n_rem == 2) state_remove(c, rem[1]);
+    } else if (n_rem) state_remove(c, rem[0]);
+    else if (n_add) state_add(c, &add[0]);
   }
   if (out) {
     out->dE = dE; out->fwd = fwd; out->bwd = bwd; out->log_alpha = log_alpha; out->T = c->T;
@@ -663,6 +793,7 @@ static void do_step(orc_ctx *c, const orc_proposal *pr, orc_step_out *out) {
 int orc_replay(orc_ctx *c, int n, const orc_proposal *tape, orc_step_out *out) {
   for (int i = 0; i < n; ++i) {
     if (tape[i].target >= c->n) return -(i + 1);
+    if (tape[i].kernel == ORC_K_MERGE && tape[i].param_id >= 0 && (tape[i].param_id >= c->n || tape[i].param_id == tape[i].target)) return -(i + 1);
     do_step(c, &tape[i], out ? &out[i] : NULL);
   }
   return 0;
@@ -677,7 +808,7 @@ int orc_run(orc_ctx *c, int64_t n_steps, uint64_t seed, uint32_t chain, orc_step
       orc_philox(ctr, key, w + 4 * b);
     }
     orc_proposal pr;
-    draw_proposal(c, w, &pr);
+    draw_proposal(c, w, &pr, key, s, chain);
     if (props) props[i] = pr;
     do_step(c, &pr, out ? &out[i] : NULL);
   }

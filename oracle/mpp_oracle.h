@@ -75,7 +75,9 @@ typedef struct {
 /* proposal kernels, make_kernels.py:50-177; order = the reference's kernel list */
 enum {
   ORC_K_UBIRTH = 0, ORC_K_UDEATH, ORC_K_DBIRTH, ORC_K_DDEATH,
-  ORC_K_GTRANS, ORC_K_DTRANS, ORC_K_GTRANSF, ORC_K_DTRANSF, ORC_NKERNEL
+  ORC_K_GTRANS, ORC_K_DTRANS, ORC_K_GTRANSF, ORC_K_DTRANSF,
+  ORC_K_SPLIT, ORC_K_MERGE,           /* split_and_merge_kernels.py:40-178, only with use_split_merge */
+  ORC_NKERNEL
 };
 
 typedef struct {
@@ -87,12 +89,16 @@ typedef struct {
   int32_t cyclic[3];
   double vmin[3], vmax[3];
   double edges[3][ORC_NCLASS];
+  double split_radius;       /* 16    make_kernels.py:148 (pos_radius = merge_radius) */
+  double split_sigma;        /* 0.1   make_kernels.py:150 (x mark range) */
 } orc_kernels;
 
 /* one tape record: a fully specified proposal (replay) */
 typedef struct {
   int32_t kernel;
   int32_t target;            /* slot of the removed/moved point, -1 if none */
+                             /* split: target = the split point, (aux0, aux1) = position delta, (as, ar, aa) =
+                              * mark deltas.  merge: target = p0, param_id = p1 (-1: p0 has no neighbour) */
   int32_t ax, ay;            /* proposed point (birth / moved / transformed) */
   double as, ar, aa;
   double aux0, aux1;         /* raw normal deltas of the Gaussian kernels */

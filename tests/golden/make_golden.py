@@ -95,7 +95,12 @@ def log_setup():
     return s, comb
 
 
-def rect_row(p):
+def rect_row(p, which=0):
+    """row of a point; ``p`` may be a list (split adds two points, merge removes two): ``which`` selects"""
+    if isinstance(p, (list, tuple)):
+        p = p[which] if which < len(p) else None
+    elif which > 0:
+        p = None
     if p is None:
         return [np.nan] * 5
     return [float(p.x), float(p.y), float(p.size), float(p.ratio), float(p.angle)]
@@ -117,7 +122,7 @@ class RecordingRNG:
         return v
 
 
-def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive"):
+def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive", use_split_merge=False):
     image_data = image_data_from(tile)
     rng = RecordingRNG(np.random.default_rng(seed))
     stash = {}
@@ -175,15 +180,17 @@ def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive"):
         summ = orig_step(self, return_state=return_state)
         u = stash["pert"]
         data = u.data or {}
-        delta = np.atleast_1d(np.asarray(data.get("delta", [np.nan, np.nan]), dtype=float))
+        delta = np.atleast_1d(np.asarray(data.get("delta", data.get("pos_delta", [np.nan, np.nan])), dtype=float))
         if delta.size == 1:
             delta = np.array([delta[0], np.nan])
+        sd = np.asarray(data.get("shape_delta", [np.nan] * 3), dtype=float)
         rows.append([stash["kernel"]] + rect_row(u.removal) + rect_row(u.addition) +
                     [delta[0], delta[1], float(data.get("param_id", -1)),
                      float(data.get("new_param_class_value", -1)),
                      stash["dE"], stash["fwd"], stash["bwd"], rng.last_random,
                      float(bool(summ.move_accepted)), float(n_before), float(temp),
-                     float(summ.n_points)])
+                     float(summ.n_points)] + rect_row(u.removal, 1) + rect_row(u.addition, 1) +
+                    [sd[0], sd[1], sd[2], float(data.get("n_neighbors", -1))])
         return summ
 
     ref_sample.make_kernels = make_kernels_rec
@@ -192,7 +199,8 @@ def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive"):
     ref_sample.naive_detection = naive_rec
     try:
         res = ref_sample.sample_rjmcmc(image_data, rng=rng, num_samples=1, energy_combinator=comb,
-                                       init_config=init, energy_setup=setup, **rjmcmc_params)
+                                       init_config=init, energy_setup=setup, use_split_merge=use_split_merge,
+                                       **rjmcmc_params)
     finally:
         ref_sample.make_kernels = orig_make_kernels
         ref_rjmcmc.RJMCMC.step = orig_step
@@ -200,7 +208,8 @@ def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive"):
         ref_sample.naive_detection = orig_naive
     final = np.array([rect_row(p) for p in res[-1]], dtype=float).reshape(-1, 5)
     cols = ["kernel", "rx", "ry", "rs", "rr", "ra", "ax", "ay", "as", "ar", "aa", "delta0", "delta1",
-            "param_id", "new_class", "dE", "fwd", "bwd", "u_accept", "accepted", "n_before", "T", "n_after"]
+            "param_id", "new_class", "dE", "fwd", "bwd", "u_accept", "accepted", "n_before", "T", "n_after",
+            "r2x", "r2y", "r2s", "r2r", "r2a", "a2x", "a2y", "a2s", "a2r", "a2a", "sd0", "sd1", "sd2", "n_neighbors"]
     if init == "gt":
         stash["init"] = np.array([rect_row(p) for p in image_data.gt_config], dtype=float).reshape(-1, 5)
     elif init is None:
@@ -246,6 +255,20 @@ def make_tapes():
     params = dict(init_temperature=5.0, target_temperature=0.0, alpha_t=0.995, burn_in=1200, samples_interval=1)
     save_tape("tape_log_64_empty.npz", t, record_tape(t, s, c, seed=3, rjmcmc_params=params, init=None),
               "no-calibration", params, extra=dict(noise=0.15, noise_seed=77 + 4))
+
+
+def make_split_merge_tapes():
+    """use_split_merge=True (split_and_merge_kernels.py): a quarter of the proposals split one point or merge two"""
+    t = synth.make_tile(96, 20, tile_id=6, noise=0.15)
+    s, c = hrc_setup()
+    params = dict(init_temperature=1.0, target_temperature=0.0, alpha_t=0.997, burn_in=2400, samples_interval=50)
+    save_tape("tape_hrc_96_sm.npz", t, record_tape(t, s, c, seed=4, rjmcmc_params=params, use_split_merge=True),
+              "legacy", params, extra=dict(noise=0.15, noise_seed=77 + 6))
+    t = synth.make_tile(64, 10, tile_id=7, noise=0.15)
+    s, c = log_setup()
+    params = dict(init_temperature=2.0, target_temperature=0.0, alpha_t=0.996, burn_in=1600, samples_interval=1)
+    save_tape("tape_log_64_sm.npz", t, record_tape(t, s, c, seed=5, rjmcmc_params=params, use_split_merge=True),
+              "no-calibration", params, extra=dict(noise=0.15, noise_seed=77 + 7))
 
 
 def make_delta_cases():
@@ -395,6 +418,8 @@ if __name__ == "__main__":
         make_perturbation_golden()
     if "tapes" in what:
         make_tapes()
+    if "sm" in what or "tapes" in what:
+        make_split_merge_tapes()
     if "delta" in what:
         make_delta_cases()
     if "unet" in what:

@@ -62,7 +62,8 @@ class Tape:
         self.intensity = float(z["intensity"])
         self.E0 = float(z["E0"])
         self.setup, self.comb, self.model = model_for(self.setup_name)
-        self.kernels = kernels.make_kernels(mappings.default_mappings(), self.intensity)
+        self.kernels = kernels.make_kernels(mappings.default_mappings(), self.intensity,
+                                            use_split_merge=len(self.p_kernels) == 10)
         self.proposals = self._proposals()
 
     def col(self, name):
@@ -90,6 +91,24 @@ class Tape:
             p = out[i]
             p["kernel"] = int(row[c["kernel"]])
             p["target"] = state.index(rem) if has_rem else -1
+            if p["kernel"] in (8, 9):              # split / merge (tapes recorded with use_split_merge)
+                rem2 = tuple(row[c["r2x"]:c["r2x"] + 5])
+                add2 = tuple(row[c["a2x"]:c["a2x"] + 5])
+                p["param_id"], p["new_class"], p["u_accept"] = -1, -1, row[c["u_accept"]]
+                if p["kernel"] == 8 and has_rem:   # target, position delta, mark deltas
+                    p["aux0"], p["aux1"] = row[c["delta0"]], row[c["delta1"]]
+                    p["as"], p["ar"], p["aa"] = row[c["sd0"]], row[c["sd1"]], row[c["sd2"]]
+                elif p["kernel"] == 9 and has_rem:
+                    p["param_id"] = state.index(rem2)
+                if row[c["accepted"]] > 0 and has_rem:
+                    state[p["target"]] = add
+                    if p["kernel"] == 8:
+                        state.append(add2)
+                    else:
+                        j = p["param_id"]
+                        state[j] = state[-1]
+                        state.pop()
+                continue
             if has_add:
                 p["ax"], p["ay"], p["as"], p["ar"], p["aa"] = int(add[0]), int(add[1]), add[2], add[3], add[4]
             p["aux0"] = 0.0 if np.isnan(row[c["delta0"]]) else row[c["delta0"]]

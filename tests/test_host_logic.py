@@ -53,10 +53,13 @@ def test_aggregate_perturbations():
 
 def test_kernel_mixture_is_the_reference_one():
     k = kernels.make_kernels(mappings.default_mappings(), 7)
-    np.testing.assert_allclose(k.p_kernel, [1 / 18, 1 / 18, 1 / 9, 1 / 9, 1 / 9, 2 / 9, 1 / 9, 2 / 9], rtol=1e-15)
+    np.testing.assert_allclose(k.p_kernel, [1 / 18, 1 / 18, 1 / 9, 1 / 9, 1 / 9, 2 / 9, 1 / 9, 2 / 9, 0, 0], rtol=1e-15)
     assert k.intensity == 7 and k.max_delta == 8 and k.sigma_trans == 2.0 and k.sigma_transform == 0.1
-    with pytest.raises(NotImplementedError):
-        kernels.make_kernels(mappings.default_mappings(), 1, use_split_merge=True)
+    # use_split_merge: four top-level branches of weight 1 (make_kernels.py:75-77), split and merge half of theirs each
+    ks = kernels.make_kernels(mappings.default_mappings(), 1, use_split_merge=True)
+    np.testing.assert_allclose(ks.p_kernel, [1 / 24, 1 / 24, 1 / 12, 1 / 12, 1 / 12, 1 / 6, 1 / 12, 1 / 6, 1 / 8, 1 / 8],
+                               rtol=1e-15)
+    assert ks.split_radius == 16.0 and ks.split_sigma == 0.1
 
 
 def test_energy_tables():
