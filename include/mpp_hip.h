@@ -32,7 +32,7 @@ extern "C" {
 #define MPP_MAX_UNIT 8
 #define MPP_MAX_PAIR 2
 #define MPP_NCLASS 32
-#define MPP_NKERNEL 8
+#define MPP_NKERNEL 10
 
 /* unit energies: models/mpp/energies/data_energies.py, prior_energies.py */
 enum {
@@ -79,19 +79,23 @@ typedef struct {
 
 /* kernel mixture, rjmcmc_sampler/kernels/make_kernels.py:50-177 (same order as its list) */
 enum { MPP_K_UBIRTH = 0, MPP_K_UDEATH, MPP_K_DBIRTH, MPP_K_DDEATH, MPP_K_GTRANS, MPP_K_DTRANS,
-       MPP_K_GTRANSF, MPP_K_DTRANSF };
+       MPP_K_GTRANSF, MPP_K_DTRANSF,
+       MPP_K_SPLIT, MPP_K_MERGE };   /* kernels/split_and_merge_kernels.py:40-178; p = 0 unless use_split_merge */
 typedef struct {
   double p_kernel[MPP_NKERNEL];
   double sigma_trans;      /* 2   */
   double sigma_transform;  /* 0.1 */
   int32_t max_delta;       /* 8   */
   int32_t _pad;
+  double split_radius;     /* 16  make_kernels.py:148 (SplitSampler.pos_radius = merge_radius) */
+  double split_sigma;      /* 0.1 make_kernels.py:150 (x mark range) */
 } mpp_kernels;
 
 /* one fully specified proposal (tape replay); custom_types/perturbation.py:7-12 flattened */
 typedef struct {
   int32_t kernel;
-  int32_t target;          /* slot removed / moved, -1 if none */
+  int32_t target;          /* slot removed / moved, -1 if none.  Split: the split point, (aux0, aux1) = position
+                            * delta, (as, ar, aa) = mark deltas.  Merge: target = p0, param_id = p1 (-1: none) */
   int32_t ax, ay;          /* proposed point */
   double as, ar, aa;
   double aux0, aux1;       /* raw normal deltas of the Gaussian kernels (Perturbation.data['delta']) */

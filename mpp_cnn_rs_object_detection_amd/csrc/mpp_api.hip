@@ -94,7 +94,7 @@ static const char *chain_error_text(int e) {
   return "unknown chain error";
 }
 
-extern "C" int mpp_abi_version(void) { return 1; }
+extern "C" int mpp_abi_version(void) { return 2; }   // 2: ten kernels (split, merge), mpp_kernels.split_*
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -109,6 +109,7 @@ extern "C" int mpp_create(int device_id, mpp_ctx **out) {
   mpp_ctx *c = new mpp_ctx();
   c->device = device_id;
   memset(&c->hp, 0, sizeof(DevParams));
+  c->hp.n_kernels = MPP_K_SPLIT;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess ||
       hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
       hipMalloc((void **)&c->dp, sizeof(DevParams)) != hipSuccess) {
@@ -270,6 +271,10 @@ extern "C" int mpp_set_kernels(mpp_ctx *c, const mpp_kernels *k, const double *i
   }
   if (fabs(acc - 1.0) > 1e-8) return fail(c, -1, "kernel probabilities do not sum to 1");   // make_kernels.py:164-172
   if (k->max_delta < 0 || k->max_delta > 15) return fail(c, -1, "max_delta must be in 0..15");
+  // 8 kernels unless split / merge carry probability (the cumulative table is searched up to the last active one)
+  c->hp.n_kernels = (k->p_kernel[MPP_K_SPLIT] > 0.0 || k->p_kernel[MPP_K_MERGE] > 0.0) ? MPP_NKERNEL : MPP_K_SPLIT;
+  if (c->hp.n_kernels == MPP_NKERNEL && !(k->split_radius > 0.0 && k->split_sigma > 0.0))
+    return fail(c, -1, "split/merge kernels need split_radius > 0 and split_sigma > 0");
   if (!c->have_kernels || c->hp.kern.max_delta != k->max_delta) c->box_dirty = true;
   c->hp.kern = *k;
   c->have_kernels = true;
@@ -595,6 +600,8 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   HIPCHK(c, hipEventRecord(c->ev0, c->stream));
   // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
   const int occ = (grid >= 1024) ? 2 : 1;
+  if (c->hp.n_kernels > MPP_K_SPLIT && !(c->lanes == 0 && (c->spec == 1 || c->spec == 8)))
+    return fail(c, -1, "the split / merge kernels are built for spec_waves 1 or 8 with spec_lanes 0");
   HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
                              d_tape, trace_tile, d_out, d_props));
   HIPCHK(c, hipEventRecord(c->ev1, c->stream));

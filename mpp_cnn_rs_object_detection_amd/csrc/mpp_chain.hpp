@@ -793,7 +793,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   const DevParams *P = c.P;
   double uk = u53(w[0], w[1]);
   int k = 0;
-  while (k < MPP_NKERNEL - 1 && P->p_cum[k] <= uk) ++k;
+  while (k < P->n_kernels - 1 && P->p_cum[k] <= uk) ++k;
   r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1;
   r.aux0 = r.aux1 = 0.0; r.ax = r.ay = 0; r.as = r.ar = r.aa = 0.0; r.rx = r.ry = 0;
   r.u_acc = u53(w[10], w[11]);
@@ -885,7 +885,11 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     r.pid = pid; r.ncls = cls;
     *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
   }
-  r.ax = q.x; r.ay = q.y; r.as = q.s; r.ar = q.r; r.aa = q.a;
+  // (materialised here through an empty asm: in the traced instantiation the compiler otherwise lost the row of the
+  // data-driven transform branch -- r.ax came out as 0 -- when the kernel grew; ROCm 7.2 hipcc)
+  int fx = q.x, fy = q.y;
+  asm volatile("" : "+v"(fx), "+v"(fy));
+  r.ax = fx; r.ay = fy; r.as = q.s; r.ar = q.r; r.aa = q.a;
 }
 
 // n-independent parts of the forward / backward proposal probabilities.  The symmetric Gaussian

@@ -34,6 +34,7 @@ struct DevParams {
   int32_t uniform_bins; // the mark edges are linspace(vmin,vmax,33)[:-1] (checked on the host)
   int32_t maxd2[MPP_MAX_PAIR];   // floor(max_dist^2): d <= max_dist  <=>  d2 <= maxd2 for integer d2
   int32_t conflict_d2;  // (2*max_inter)^2 + 1: two proposals further apart cannot influence each other
+  int32_t n_kernels;    // 8, or 10 when the split / merge kernels carry probability
   int32_t force_accept; // apply every proposal (perturbation_sampler.py:162-166 walks kernels without accept/reject)
   double inv_step[3];   // 32 / (vmax - vmin)
 };

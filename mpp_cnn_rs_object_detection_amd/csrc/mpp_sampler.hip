@@ -1,5 +1,6 @@
 // mpp_sampler.hip -- the chain kernels (see mpp_chain.hpp for the design notes and the shared pieces)
 #include "mpp_chain.hpp"
+#include "mpp_split_merge.hpp"
 
 // WAVES waves per chain.  LPW == 0: one speculative step per wave, the wave's lanes cooperate on it.
 // LPW > 0 ("lane mode"): lanes 0..LPW-1 of every wave each evaluate their own step.  SPEC steps per round.
@@ -8,7 +9,8 @@
 // OCC: minimum waves per SIMD the register allocation must allow.  The hot loop wants ~340 VGPRs, i.e. ONE
 // wave per SIMD; throughput runs over many tiles ask for OCC = 2 (256 VGPRs, a few spills) so that two chains
 // share a SIMD and hide each other's latencies.
-template <int WAVES, int LPW, bool DIAG, int OCC>
+// SM: the instantiation that also knows the split / merge kernels (mpp_split_merge.hpp); the others carry none of it.
+template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
 __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
                                                                   long long n_steps, unsigned long long seed,
                                                                   unsigned int chain0, const mpp_proposal *tape,
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
     const bool mine = (LANE ? (c.lane < LPW) : true) && (!apply_round || ri == 0);
     const long long my = done + ri;
     Rec r;
-    r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0;
+    r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r._pad = 0;
     if (mine && my < n_steps) {
       for (int i = 0; i < ri; ++i) if (T > T_target) T *= alpha;          // temperature of step `my`
       r.valid = 1;
@@ -117,8 +119,22 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         r.pid = tp.param_id; r.ncls = tp.new_class; r.u_acc = tp.u_accept; r.rx = r.ry = 0;
         bool is_birth = tp.kernel == MPP_K_UBIRTH || tp.kernel == MPP_K_DBIRTH;
         bool is_death = tp.kernel == MPP_K_UDEATH || tp.kernel == MPP_K_DDEATH;
-        if (tp.kernel < 0 || tp.kernel >= MPP_NKERNEL) { r.valid = 0; r.kernel = -1; }
+        const bool is_sm = tp.kernel == MPP_K_SPLIT || tp.kernel == MPP_K_MERGE;
+        if (tp.kernel < 0 || tp.kernel >= MPP_NKERNEL || (is_sm && !SM)) { r.valid = 0; r.kernel = -1; }
         else if (is_birth) r.has_add = 1;
+        else if (is_sm) {                  // split: target; merge: target = p0, param_id = p1 (-1: no neighbour)
+          const bool empty = tp.target < 0 || n == 0 || (tp.kernel == MPP_K_MERGE && (n < 2 || tp.param_id < 0));
+          if (!empty) {
+            if (tp.target >= n || (tp.kernel == MPP_K_MERGE && (tp.param_id >= n || tp.param_id == tp.target))) {
+              r.valid = 0; r.kernel = -1;
+            } else {
+              r.has_rem = 1;
+              r.tslot = L.order[tp.target];
+              int xy = L.xy[r.tslot];
+              r.rx = xy & 0xffff; r.ry = (xy >> 16) & 0xffff;
+            }
+          } else r.tidx = -1;
+        }
         else if (n > 0 && tp.target >= 0) {
           if (tp.target >= n) { r.valid = 0; r.kernel = -1; }       // reported at commit time
           else {
@@ -128,7 +144,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
             r.rx = xy & 0xffff; r.ry = (xy >> 16) & 0xffff;
           }
         }
-        if (r.valid && (tp.kernel == MPP_K_DTRANSF || tp.kernel == MPP_K_GTRANSF) && r.has_rem &&
+        if (r.valid && !is_sm && (tp.kernel == MPP_K_DTRANSF || tp.kernel == MPP_K_GTRANSF) && r.has_rem &&
             (tp.param_id < 0 || tp.param_id > 2 || (tp.kernel == MPP_K_DTRANSF && (tp.new_class < 0 || tp.new_class >= MPP_NCLASS)))) {
           r.valid = 0; r.kernel = -1;
         }
@@ -139,10 +155,25 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         for (uint32_t b = 0; b < 3; ++b)
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
         draw_proposal<LANE>(c, w, n, r, &keep);
+        if (SM && r.kernel >= MPP_K_SPLIT) {
+          int e = 0;
+          sm_draw(c, r, ri, n, w, k0, k1, s, chain0 + (uint32_t)tile, &e);
+          if (e) { r.valid = 0; r.kernel = -2 - e; }
+        } else if (!SM && r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
       }
       PROF_ADD(0);
       if (r.valid && r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
-      if (r.valid) {
+      if (SM && r.valid && r.kernel >= MPP_K_SPLIT && r.has_rem) {
+        // a two-point change runs alone on the live state: ask for an apply round, or (in it) do the whole step
+        r.dE = 0.0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
+        r.qf = r.qb = 1.0;
+        if (!apply_round) { r.accepted = 1; r.n_stash = STASH + 1; }
+        else {
+          int e = 0;
+          sm_step(c, r, ri, n, T, tracing, &e);
+          if (e) { r.valid = 0; r.kernel = -2 - e; }
+        }
+      } else if (r.valid) {
 #ifdef MPP_PROFILE
         evaluate<LANE>(c, r, ri, keep, n, T, tracing, apply_round, prof_);
 #else
@@ -166,6 +197,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       // commit record q (an accepted step that changes the configuration); returns true when the round must end
       // after it (population or index->slot map changed, or an error)
       auto commit_one = [&](const Rec &q, int w) -> bool {
+        if (SM && q._pad != 0) { cur_n += q._pad; return true; }      // a split / merge applied by sm_step()
         if (!apply_round && c.lane < q.n_stash) {
           int u = L.stash_slot[w * STASH + c.lane];
           L.red0[u] = L.stash_v0[w * STASH + c.lane];
@@ -352,14 +384,14 @@ extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec
   return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n, waves);
 }
 
-template <int WAVES, int LPW, bool DIAG, int OCC>
+template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
 static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                               long long n_steps, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
-  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC>,
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
+  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
                      n_steps, seed, chain0, tape, trace_tile, out, props);
   return hipGetLastError();
 }
@@ -369,11 +401,20 @@ static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevPar
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props,
                               int occ) {
   constexpr int BASE = (WAVES + 3) / 4;      // waves per SIMD one workgroup needs anyway
-  if (tape || out || props)
-    return launch_spec_d<WAVES, LPW, true, BASE>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+  const bool diag = tape || out || props;
+  if (P->n_kernels > MPP_K_SPLIT) {          // split / merge kernels in the mixture: built for 1 and 8 waves
+    if constexpr (LPW == 0 && (WAVES == 1 || WAVES == 8)) {
+      if (diag) return launch_spec_d<WAVES, LPW, true, BASE, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+      return launch_spec_d<WAVES, LPW, false, BASE, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+    } else {
+      return hipErrorNotSupported;
+    }
+  }
+  if (diag)
+    return launch_spec_d<WAVES, LPW, true, BASE, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
   if (WAVES <= 4 && LPW == 0 && occ >= 2)
-    return launch_spec_d<WAVES, LPW, false, 2>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
-  return launch_spec_d<WAVES, LPW, false, BASE>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+    return launch_spec_d<WAVES, LPW, false, 2, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+  return launch_spec_d<WAVES, LPW, false, BASE, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
 }
 
 // spec = steps evaluated per round; lanes = 0: one wave per step (spec waves); lanes > 0: 4 waves x lanes lanes

@@ -18,7 +18,7 @@ from .kernels import KernelDesc
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MPP_LIB_PATH") or os.path.join(_HERE, "libmppgpu.so")   # override: diagnostic builds only
 
-MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 8
+MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 
 #: every symbol include/mpp_hip.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
@@ -52,7 +52,7 @@ class MappingsC(C.Structure):
 
 class KernelsC(C.Structure):
     _fields_ = [("p_kernel", C.c_double * NKERNEL), ("sigma_trans", C.c_double), ("sigma_transform", C.c_double),
-                ("max_delta", C.c_int32), ("_pad", C.c_int32)]
+                ("max_delta", C.c_int32), ("_pad", C.c_int32), ("split_radius", C.c_double), ("split_sigma", C.c_double)]
 
 
 PROPOSAL_DTYPE = np.dtype([("kernel", "<i4"), ("target", "<i4"), ("ax", "<i4"), ("ay", "<i4"),
@@ -150,8 +150,9 @@ def mappings_struct(mappings) -> MappingsC:
 def kernels_struct(kd: KernelDesc) -> KernelsC:
     k = KernelsC()
     for i in range(NKERNEL):
-        k.p_kernel[i] = float(kd.p_kernel[i])
+        k.p_kernel[i] = float(kd.p_kernel[i]) if i < len(kd.p_kernel) else 0.0
     k.sigma_trans, k.sigma_transform, k.max_delta = float(kd.sigma_trans), float(kd.sigma_transform), int(kd.max_delta)
+    k.split_radius, k.split_sigma = float(getattr(kd, "split_radius", 16.0)), float(getattr(kd, "split_sigma", 0.1))
     return k
 
 

@@ -16,6 +16,8 @@ from __future__ import annotations
 from copy import copy
 from typing import List, Sequence, Tuple
 
+import math
+
 import numpy as np
 
 from . import energies as E
@@ -107,7 +109,40 @@ def aggregate_perturbations(perturbations: Sequence[Perturbation]) -> Perturbati
     return Perturbation(type=DummyKernel, removal=list(removed), addition=list(added))
 
 
-def _walk(ctx: MppContext, start: Sequence[Rectangle], n_iter: int, seed: int, chain: int):
+def _clip_mark(mapping, v: float) -> float:
+    """ValueMapping.clip (shape_net/mappings.py:52-58) in the arithmetic of the device code"""
+    lo, hi = float(mapping.v_min), float(mapping.v_max)
+    if mapping.is_cyclic:
+        return math.fmod(v - lo, hi - lo) + (hi - lo if math.fmod(v - lo, hi - lo) < 0 else 0.0) + lo
+    return lo if v < lo else (hi if v > hi else v)
+
+
+def _clip_int(v: float, hi: int) -> int:
+    return int(0.0 if v < 0.0 else (float(hi) if v > hi else v))
+
+
+def split_rectangles(p: Rectangle, pos_delta, shape_delta, shape, mappings):
+    """the two rectangles a split makes of ``p`` (split_and_merge_kernels.py:56-73)"""
+    H, W = shape[:2]
+    marks = (p.size, p.ratio, p.angle)
+    out = []
+    for sgn in (-1.0, 1.0):
+        m = [_clip_mark(mp, mk + sgn * d) for mp, mk, d in zip(mappings, marks, shape_delta)]
+        out.append(Rectangle(_clip_int(p.x + sgn * pos_delta[0], H - 1), _clip_int(p.y + sgn * pos_delta[1], W - 1),
+                             size=m[0], ratio=m[1], angle=m[2]))
+    return out
+
+
+def merged_rectangle(p0: Rectangle, p1: Rectangle, shape, mappings) -> Rectangle:
+    """split_and_merge_kernels.py:128-135 (the column is clipped with shape[0] upstream; reproduced)"""
+    H = shape[0]
+    m = [_clip_mark(mp, (a + b) / 2.0) for mp, a, b in zip(mappings, (p0.size, p0.ratio, p0.angle),
+                                                          (p1.size, p1.ratio, p1.angle))]
+    return Rectangle(_clip_int((p0.x + p1.x) / 2.0, H - 1), _clip_int((p0.y + p1.y) / 2.0, H - 1),
+                     size=m[0], ratio=m[1], angle=m[2])
+
+
+def _walk(ctx: MppContext, start: Sequence[Rectangle], n_iter: int, seed: int, chain: int, shape=None, mappings=None):
     """n_iter always-applied kernel proposals from `start`; returns (perturbations, final points)."""
     xy = np.array([[p.x, p.y] for p in start], dtype=np.int32).reshape(-1, 2)
     mk = np.array([[p.size, p.ratio, p.angle] for p in start], dtype=np.float64).reshape(-1, 3)
@@ -128,6 +163,23 @@ def _walk(ctx: MppContext, start: Sequence[Rectangle], n_iter: int, seed: int, c
             state.append(new)
         elif t < 0:
             perts.append(Perturbation(type=kind))                  # empty configuration: nothing to do
+        elif k == 8:                                               # split: state[t] -> a0 (same slot), a1 appended
+            pd, sd = (float(pr["aux0"]), float(pr["aux1"])), (float(pr["as"]), float(pr["ar"]), float(pr["aa"]))
+            a0, a1 = split_rectangles(state[t], pd, sd, shape, mappings)
+            perts.append(Perturbation(type=kind, removal=state[t], addition=[a0, a1],
+                                      data={"pos_delta": pd, "shape_delta": sd}))
+            state[t] = a0
+            state.append(a1)
+        elif k == 9:                                               # merge: q takes p0's slot, p1 is swap-removed
+            j = int(pr["param_id"])
+            if j < 0:
+                perts.append(Perturbation(type=kind))
+                continue
+            q = merged_rectangle(state[t], state[j], shape, mappings)
+            perts.append(Perturbation(type=kind, removal=[state[t], state[j]], addition=q))
+            state[t] = q
+            state[j] = state[-1]
+            state.pop()
         elif is_death:
             perts.append(Perturbation(type=kind, removal=state[t]))
             state[t] = state[-1]
@@ -162,7 +214,7 @@ def sample_multiple_kernel_perturbations(image_data: ImageWMaps, n_samples: int,
     seed = int(rng.integers(0, 2 ** 63 - 1))
     results, perts_out = [], []
     for s in range(n_samples):
-        perts, final = _walk(ctx, start, n_iter, seed, chain=s)
+        perts, final = _walk(ctx, start, n_iter, seed, chain=s, shape=image_data.shape, mappings=image_data.mappings)
         results.append(EPointsSet(final, image_data.shape, unit, pair, image_data=image_data, _ctx=ctx))
         perts_out.append(aggregate_perturbations(perts) if aggregate_pert else perts)
     return perts_out if return_perturbations else results

@@ -8,7 +8,7 @@ Differences a caller can observe (both documented in DESIGN.md):
 
 * the proposal stream is Philox4x32-10 keyed by a seed drawn from the given ``rng`` (the reference
   consumes the NumPy generator directly and is not reproducible run to run);
-* ``use_split_merge`` is not built (both shipped configs leave it off).
+* with ``use_split_merge`` the kernel needs ``spec_waves`` 1 or 8 (split / merge steps run alone on the live state).
 """
 from __future__ import annotations
 
@@ -59,7 +59,9 @@ class TileBatchSampler:
     """All tiles of an image (or of a batch of images) sampled concurrently on one GPU."""
 
     def __init__(self, tiles: Sequence[ImageWMaps], energy_setup, energy_combinator, device: int = 0,
-                 point_capacity: int = 1024, spec_waves: int = 8, ctx: Optional[MppContext] = None):
+                 point_capacity: int = 1024, spec_waves: int = 8, ctx: Optional[MppContext] = None,
+                 use_split_merge: bool = False):
+        self.use_split_merge = use_split_merge
         shapes = {tuple(t.shape[:2]) for t in tiles}
         if len(shapes) != 1:
             raise ValueError(f"all tiles of a batch must have the same shape, got {shapes}")
@@ -100,7 +102,7 @@ class TileBatchSampler:
                 self.ctx.set_points(i, xy, mk)
         counts = np.array([self.ctx.count(i) for i in range(n)], dtype=np.float64)
         self.intensity = np.maximum(1.0, counts)             # reference sample_rjmcmc.py:68
-        self.ctx.set_kernels(make_kernels(self.mappings, 1.0), intensity=self.intensity)
+        self.ctx.set_kernels(make_kernels(self.mappings, 1.0, use_split_merge=self.use_split_merge), intensity=self.intensity)
 
     def run(self, total_steps: int, snapshot_steps: Sequence[int], num_samples: int, T0: float, alpha: float,
             T_target: float, seed: int, chain0: int = 0):
@@ -131,12 +133,10 @@ def sample_rjmcmc_batch(tiles: Sequence[ImageWMaps], rng: np.random.Generator, n
                         use_split_merge: bool = False, device: int = 0, spec_waves: int = 8,
                         point_capacity: int = 1024, chain0: int = 0):
     """``sample_rjmcmc`` for many equally-shaped tiles at once; returns one result list per tile."""
-    if use_split_merge:
-        raise NotImplementedError("split/merge kernels are not built (reference split_and_merge_kernels.py)")
     alpha, T_target, total, snaps = resolve_schedule(num_samples, init_temperature, alpha_t, burn_in, samples_interval,
                                                       target_temperature, iter_multiplier)
     sampler = TileBatchSampler(tiles, energy_setup, energy_combinator, device=device, spec_waves=spec_waves,
-                               point_capacity=point_capacity)
+                               point_capacity=point_capacity, use_split_merge=use_split_merge)
     sampler.init(init_config)
     seed = int(rng.integers(0, 2 ** 63 - 1))
     start = time.perf_counter()

@@ -666,6 +666,7 @@ static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *
     int *nb = (int *)malloc(sizeof(int) * (size_t)(n + 1));
     int cnt = merge_neighbours(c, t, nb);
     pr->param_id = cnt > 0 ? nb[mulhi(w[3], (uint32_t)cnt)] : -1;
+    if (cnt == 0) pr->target = -1;        /* p0 has no neighbour: an empty perturbation, nothing is removed */
     free(nb);
     return;
   }

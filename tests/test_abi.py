@@ -26,7 +26,7 @@ def test_library_exports_every_symbol(lib_path):
     L = ctypes.CDLL(lib_path)
     for name in hip_api.ABI_SYMBOLS:
         assert hasattr(L, name), name
-    assert L.mpp_abi_version() == 1
+    assert L.mpp_abi_version() == 2
 
 
 def test_struct_sizes_match_the_header(lib_path):
@@ -35,7 +35,7 @@ def test_struct_sizes_match_the_header(lib_path):
     assert ctypes.sizeof(hip_api.PairTermC) == 16 + 16 + 16
     assert ctypes.sizeof(hip_api.ModelC) == 16 + 16 + 8 * 80 + 2 * 48
     assert ctypes.sizeof(hip_api.MappingsC) == 16 + 24 + 24 + 3 * 32 * 8
-    assert ctypes.sizeof(hip_api.KernelsC) == 64 + 16 + 8
+    assert ctypes.sizeof(hip_api.KernelsC) == 80 + 16 + 8 + 16
     assert hip_api.PROPOSAL_DTYPE.itemsize == 72 and hip_api.STEPOUT_DTYPE.itemsize == 48
 
 

@@ -13,12 +13,12 @@ from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings, synth
 pytestmark = pytest.mark.gpu
 
 
-def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, lanes=0):
+def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, lanes=0, split_merge=False):
     t = synth.make_tile(tile, n_obj, tile_id=tile_id, noise=noise)
     setup, comb, model = model_for(setup_name)
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kernels.make_kernels(mappings.default_mappings(), 1.0))
     xy, marks = o.naive_detection(setup.detection_threshold, 6.0)
-    kd = kernels.make_kernels(mappings.default_mappings(), max(1, len(xy)))
+    kd = kernels.make_kernels(mappings.default_mappings(), max(1, len(xy)), use_split_merge=split_merge)
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kd)
     o.set_points(xy, marks)
     ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec, spec_lanes=lanes)
@@ -57,6 +57,39 @@ def test_chain_matches_oracle(setup_name, T0, alpha):
     np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
     assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-9)
     assert ctx.step_index() == n_steps
+
+
+@pytest.mark.parametrize("setup_name,T0,alpha", [("legacy", 1.0, 0.998), ("no-calibration", 2.0, 0.997)])
+def test_split_merge_chain_matches_oracle(setup_name, T0, alpha):
+    """use_split_merge (split_and_merge_kernels.py): a quarter of the proposals split one point or merge two; the
+    kernel does them as two one-point changes on the live state and undoes them when rejected"""
+    n_steps, seed = 5000, 77
+    t, o, ctx = setup_case(128, 40, setup_name, tile_id=5, split_merge=True)
+    o.set_temperature(T0, alpha, 0.0)
+    ctx.set_schedule(T0, alpha, 0.0)
+    oout, oprops = o.run(n_steps, seed, chain=0, trace=True)
+    gout, gprops = ctx.run(n_steps, seed, chain0=0, trace_tile=0)
+    k = oprops["kernel"]
+    assert (k == 8).sum() > 400 and (k == 9).sum() > 400
+    assert oout["accepted"][(k == 8) & (oprops["target"] >= 0)].sum() > 20           # splits really happen
+    assert oout["accepted"][(k == 9) & (oprops["param_id"] >= 0)].sum() > 5          # and merges
+    compare_traces(gout, gprops, oout, oprops)
+    gxy, gm = ctx.get_points()
+    oxy, om = o.get_points()
+    np.testing.assert_array_equal(gxy, oxy)
+    np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
+    assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-9)   # caches survived the undos
+    # 8 speculative waves, untraced: the same chain
+    t2, o2, ctx8 = setup_case(128, 40, setup_name, tile_id=5, split_merge=True, spec=8)
+    ctx8.set_schedule(T0, alpha, 0.0)
+    ctx8.run(n_steps, seed, chain0=0)
+    xy8, m8 = ctx8.get_points()
+    np.testing.assert_array_equal(xy8, gxy)
+    np.testing.assert_array_equal(m8, gm)
+    with pytest.raises(hip_api.MppError):
+        _, _, ctx4 = setup_case(128, 40, setup_name, tile_id=5, split_merge=True, spec=4)
+        ctx4.set_schedule(T0, alpha, 0.0)
+        ctx4.run(10, seed)
 
 
 @pytest.mark.parametrize("spec", [2, 4, 8, 16])

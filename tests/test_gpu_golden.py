@@ -25,6 +25,15 @@ def make_ctx(t: Tape, spec=1):
     return ctx
 
 
+SM_TAPES = ["tape_hrc_96_sm.npz", "tape_log_64_sm.npz"]     # recorded with use_split_merge=True
+
+
+@pytest.mark.parametrize("spec", [1, 8])
+@pytest.mark.parametrize("name", SM_TAPES)
+def test_split_merge_tape_replay(name, spec):
+    test_tape_replay(name, spec)
+
+
 @pytest.mark.parametrize("spec", [1, 4, 8, "L4", "L8"])
 @pytest.mark.parametrize("name", TAPES)
 def test_tape_replay(name, spec):

@@ -256,3 +256,39 @@ def test_borrowed_device_maps_give_the_same_chain_as_uploaded_host_maps():
     pb = sorted((p.x, p.y, p.size, p.ratio, p.angle) for p in b)
     assert pa == pb and len(pa) > 5            # (a short, still hot chain: only the equality matters here)
     np.testing.assert_allclose(sorted(sa), sorted(sb), rtol=1e-12)
+
+
+def test_split_merge_walks_and_sampling():
+    """use_split_merge through the host interfaces (sample_rjmcmc.py:38-44, perturbation_sampler.py:125-149): the
+    host replay of a kernel walk (split/merge rectangles recomputed in Python) lands on the device's final state, the
+    aggregated perturbations keep delta = E1 - E0, and a full sampling run still finds the objects."""
+    from mpp_cnn_rs_object_detection_amd.perturbation_sampler import sample_multiple_kernel_perturbations
+    from mpp_cnn_rs_object_detection_amd.point_set import EPointsSet
+    from mpp_cnn_rs_object_detection_amd.sampler import sample_rjmcmc
+    tile = synth.make_tile(128, 30, tile_id=9, noise=0.2)
+    data = image_data(tile)
+    setup, comb = hrc_model()
+    unit, pair = setup.make_energies(data)
+    base = EPointsSet(data.gt_config, data.shape, unit, pair, image_data=data)
+    data.gt_config_set = base
+    walks = sample_multiple_kernel_perturbations(data, n_samples=6, rng=np.random.default_rng(5), energy_setup=setup,
+                                                 iter_per_point=3, return_perturbations=True, aggregate_pert=False,
+                                                 use_split_merge=True)
+    kinds = {p.type for w in walks for p in w}
+    assert {"Split", "Merge"} <= kinds
+    assert any(isinstance(p.addition, list) and len(p.addition) == 2 for w in walks for p in w)
+    finals = sample_multiple_kernel_perturbations(data, n_samples=6, rng=np.random.default_rng(5), energy_setup=setup,
+                                                  iter_per_point=3, use_split_merge=True)
+    perts = sample_multiple_kernel_perturbations(data, n_samples=6, rng=np.random.default_rng(5), energy_setup=setup,
+                                                 iter_per_point=3, return_perturbations=True, aggregate_pert=True,
+                                                 use_split_merge=True)
+    e0 = base.total_energy()
+    for p, d, f in zip(perts, base.energy_delta_batch(perts), finals):
+        new = base.apply_perturbation(p, inplace=False)
+        assert abs(d - (new.total_energy() - e0)) < 1e-8
+        assert sorted((q.x, q.y, q.size, q.ratio, q.angle) for q in new) == sorted((q.x, q.y, q.size, q.ratio, q.angle) for q in f)
+    res = sample_rjmcmc(image_data(synth.make_tile(256, 50, tile_id=0)), rng=np.random.default_rng(0), num_samples=1,
+                        energy_combinator=comb, init_config="naive", init_temperature=1, alpha_t=0.999, burn_in=30000,
+                        energy_setup=setup, samples_interval=128, target_temperature=0.0, use_split_merge=True)
+    gt = synth.make_tile(256, 50, tile_id=0).gt_xy
+    assert matched(res[-1], gt) >= 48 and len(res[-1]) <= 53
