@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--tiles-per-gpu", type=int, default=1)
     ap.add_argument("--cpu-baseline-chains", type=int, default=12)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence", action="store_true", help="skip the (untimed) wall-clock-to-convergence chain")
     ap.add_argument("--batched-tiles", type=int, default=0,
                     help="extra, untimed-in-`value` measurement: this many 256x256 tiles (the reference's tile size, "
                          "50 objects, mpp_hrcM schedule of 30257 steps) sampled concurrently, one workgroup per tile")
@@ -174,6 +175,34 @@ def main():
             "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
         },
     }
+
+    if rank == 0 and T >= 1 and not args.no_convergence:
+        # Wall-clock to convergence (BASELINE metric), untimed extra chain of tile 0 run in chunks:
+        # (i) the whole schedule, (ii) time-to-quality = first chunk end with >= 95 % of the synthetic centres matched
+        # within 2 px and the energy within 1 % of its final value.  Chunked launches continue the same Philox chain.
+        chunk, done_steps, cum_ms, hist = 2000, 0, 0.0, []
+        for i, (xy, mk) in enumerate(inits):
+            ctx.set_points(i, xy, mk)
+        ctx.set_schedule(T0, alpha, Tt)
+        gt = tiles[0].gt_xy
+        while done_steps < args.iters:
+            n_run = min(chunk, args.iters - done_steps)
+            ctx.run(n_run, seed=0, chain0=rank * T)
+            cum_ms += ctx.last_kernel_ms()
+            done_steps += n_run
+            pxy, _ = ctx.get_points(0)
+            dd = np.sqrt(((pxy[:, None, :] - gt[None]) ** 2).sum(-1)) if len(pxy) else np.full((1, len(gt)), 1e9)
+            hist.append((done_steps, cum_ms, float((dd.min(axis=0) <= 2).mean()), float(ctx.total_energy(0))))
+        e_final = hist[-1][3]
+        ttq = next(((st, ms) for st, ms, m, e in hist if m >= 0.95 and abs(e - e_final) <= 0.01 * abs(e_final)), None)
+        result["config"]["convergence"] = {
+            "schedule_steps": args.iters, "schedule_wall_s": kernel_ms * 1e-3,
+            "time_to_quality_steps": ttq[0] if ttq else None,
+            "time_to_quality_s": ttq[1] * 1e-3 if ttq else None,
+            "criterion": ">= 95 % of the centres within 2 px and energy within 1 % of the final energy, checked every 2000 steps",
+            "final_energy": e_final, "final_matched_fraction": hist[-1][2],
+            "reference_probe": "reference NumPy sampler: 41.4 s for 30 257 steps of this tile (145/200 matched), BASELINE.md section 2",
+        }
 
     if rank == 0 and world == 1 and args.batched_tiles > 0:
         B, bt, bobj, biters = args.batched_tiles, args.batched_tile, args.batched_objects, 30257
