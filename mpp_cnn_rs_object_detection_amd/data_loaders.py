@@ -126,10 +126,12 @@ def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], ori
         scores = agg.papangelou_all(energy_combinator=energy_model)
         xy = np.array([[p.x, p.y] for p in merged], dtype=float)
         removed = np.zeros(len(merged), dtype=bool)
+        from scipy.spatial import cKDTree              # neighbour lists once (integer coordinates: exact comparisons)
+        balls = cKDTree(xy).query_ball_point(xy, r=float(distance))
         for i in range(len(merged)):
             if removed[i]:
                 continue
-            near = np.nonzero((np.hypot(xy[:, 0] - xy[i, 0], xy[:, 1] - xy[i, 1]) <= distance) & ~removed)[0]
+            near = np.array(sorted(j for j in balls[i] if not removed[j]), dtype=np.int64)
             if len(near) == 0:
                 continue
             best = near[np.argmax(scores[near])]
