@@ -169,9 +169,21 @@ class MPPModel:
                 **self.config["ordering_criterion"])
             save_energy_combinator(self.energy_model, self.save_path)
             return
+        if mode in ("grad_descent", "integral_criterion"):         # mpp_model.py:142-154
+            from .train_integral_criterion import train_integral_criterion
+            from .train_ordering_criterion import Logger
+
+            class _Loader2:
+                def __init__(s, data, bs): s.data, s.bs = data, bs
+                def __len__(s): return (len(s.data) + s.bs - 1) // s.bs
+                def __iter__(s): return iter(s.data.batches(s.bs))
+            self.energy_model = train_integral_criterion(
+                train_loader=_Loader2(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
+                logger=Logger(self.save_path), energy_setup=self.energy_setup, device=self.device, **self.config[mode])
+            save_energy_combinator(self.energy_model, self.save_path)
+            return
         if mode != "manual":
-            raise NotImplementedError(f"train mode {mode!r}: 'manual' and 'ordering_criterion' are built "
-                                      f"(reference mpp_model.py:137-197)")
+            raise NotImplementedError(f"train mode {mode!r} (reference mpp_model.py:137-197)")
         m = self.config["manual"]
         if isinstance(self.energy_setup, E.LegacyEnergySetup):
             self.energy_model = E.hierarchical_from_manual(m)
