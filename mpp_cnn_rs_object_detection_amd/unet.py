@@ -176,8 +176,12 @@ class ScoreMapNets:
                  dtype: torch.dtype = torch.float32, ctx=None):
         from .hip_api import MppContext
         self.device = torch.device("cuda", device)
-        self.pos = posnet.to(self.device).eval().to(memory_format=torch.channels_last)
-        self.shp = shapenet.to(self.device).eval().to(memory_format=torch.channels_last)
+        # NCHW by default: F.pad(mode="reflect") only has a contiguous-NCHW kernel, so with channels_last every
+        # 3x3 convolution paid two full layout conversions (55 % of the forward in profiles/r01_unet_ops.txt)
+        self.channels_last = os.environ.get("MPP_UNET_CHANNELS_LAST", "0") == "1"
+        fmt = torch.channels_last if self.channels_last else torch.contiguous_format
+        self.pos = posnet.to(self.device).eval().to(memory_format=fmt)
+        self.shp = shapenet.to(self.device).eval().to(memory_format=fmt)
         self.div_w, self.div_b = div_clf or (DIV_CLF_W, DIV_CLF_B)
         self.dtype = dtype
         self.ctx = ctx or MppContext(device)
@@ -189,7 +193,7 @@ class ScoreMapNets:
         img = img[..., :3].permute(2, 0, 1).float().to(self.device)
         H, W = img.shape[1:]
         padded, _ = pad_before_infer(img, self.pos.backbone.depth)
-        x = padded.unsqueeze(0).contiguous(memory_format=torch.channels_last)
+        x = padded.unsqueeze(0).contiguous(memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             pos_out = self.pos(x)
             logits = self.shp(x)
