@@ -25,9 +25,9 @@ extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const
                                        int n_cases, const int32_t *rem_off, const int32_t *rem,
                                        const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
                                        double *dE);
-extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
+extern "C" void mpp_launch_cdf(hipStream_t st, int n_tiles, const float *det, int H, int W, double *rowpart, double *rowbase,
                                double *scratch_rowtot);
-extern "C" void mpp_launch_boxsum(hipStream_t st, const double *rowpart, int H, int W, int md, double *boxsum);
+extern "C" void mpp_launch_boxsum(hipStream_t st, int n_tiles, const double *rowpart, int H, int W, int md, double *boxsum);
 extern "C" void mpp_launch_naive_init(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles,
                                       double threshold, double nms_dist, unsigned long long *cand, int cand_cap);
 extern "C" void mpp_launch_posnet_epilogue(hipStream_t st, const float *out, int H, int W, int ldh, int ldw, float w,
@@ -324,8 +324,7 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   std::vector<double> sched(T * 3);
   for (size_t t = 0; t < T; ++t) { sched[3 * t] = c->sched[0]; sched[3 * t + 1] = c->sched[1]; sched[3 * t + 2] = c->sched[2]; }
   HIPCHK(c, hipMemcpyAsync(c->T, sched.data(), sched.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  for (size_t t = 0; t < M; ++t)
-    mpp_launch_cdf(c->stream, c->det + t * hw, H, W, c->rowpart + t * hw, c->rowbase + t * (H + 1), c->rowtot + t * H);
+  mpp_launch_cdf(c->stream, (int)M, c->det, H, W, c->rowpart, c->rowbase, c->rowtot);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((int)c->intensity.size() != c->n_tiles) c->intensity.assign(c->n_tiles, 1.0);
@@ -362,8 +361,8 @@ static int push_state(mpp_ctx *c) {
   }
   if (c->box_dirty && c->have_kernels) {
     const size_t hw = (size_t)c->H * c->W;
-    for (int t = 0; t < c->n_maps; ++t)
-      mpp_launch_boxsum(c->stream, c->rowpart + t * hw, c->H, c->W, c->hp.kern.max_delta, c->boxsum + t * hw);
+    (void)hw;
+    mpp_launch_boxsum(c->stream, c->n_maps, c->rowpart, c->H, c->W, c->hp.kern.max_delta, c->boxsum);
     HIPCHK(c, hipGetLastError());
     c->box_dirty = false;
   }

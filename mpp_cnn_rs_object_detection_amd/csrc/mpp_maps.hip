@@ -11,15 +11,21 @@
 #include "mpp_device.hpp"
 
 // ---- birth CDF ---------------------------------------------------------------------------------
-__global__ void k_row_partial(const float *det, int H, int W, double *rowpart, double *rowtot) {
+// (all tiles of a context in one launch: blockIdx.y / blockIdx.x / blockIdx.z = tile)
+__global__ void k_row_partial(const float *det_all, int H, int W, double *rowpart_all, double *rowtot_all) {
+  const size_t hw = (size_t)H * W;
+  const float *det = det_all + blockIdx.y * hw;
+  double *rowpart = rowpart_all + blockIdx.y * hw, *rowtot = rowtot_all + (size_t)blockIdx.y * H;
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= H) return;
   double s = 0.0;
   for (int j = 0; j < W; ++j) { s += (double)det[(size_t)r * W + j]; rowpart[(size_t)r * W + j] = s; }
   rowtot[r] = s;
 }
-__global__ void k_row_base(const double *rowtot, int H, double *rowbase) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+__global__ void k_row_base(const double *rowtot_all, int H, double *rowbase_all) {
+  const double *rowtot = rowtot_all + (size_t)blockIdx.x * H;
+  double *rowbase = rowbase_all + (size_t)blockIdx.x * (H + 1);
+  if (threadIdx.x == 0) {
     double s = 0.0;
     for (int r = 0; r < H; ++r) { rowbase[r] = s; s += rowtot[r]; }
     rowbase[H] = s;
@@ -28,7 +34,10 @@ __global__ void k_row_base(const double *rowtot, int H, double *rowbase) {
 // sum of det over the (2*md+1)^2 window clipped to the tile, around every pixel: the normaliser of the
 // data-driven translation kernel (transform_kernels.py:70-76,94-99).  Rows are added top to bottom,
 // each row segment taken from the per-row prefix table -- the same order the sampler's draw uses.
-__global__ void k_boxsum(const double *rowpart, int H, int W, int md, double *boxsum) {
+__global__ void k_boxsum(const double *rowpart_all, int H, int W, int md, double *boxsum_all) {
+  const size_t hw = (size_t)H * W;
+  const double *rowpart = rowpart_all + blockIdx.z * hw;
+  double *boxsum = boxsum_all + blockIdx.z * hw;
   int y = blockIdx.x * blockDim.x + threadIdx.x, x = blockIdx.y;
   if (y >= W || x >= H) return;
   int x0 = max(0, x - md), x1 = min(x + md + 1, H), y0 = max(0, y - md), y1 = min(y + md + 1, W);
@@ -39,13 +48,22 @@ __global__ void k_boxsum(const double *rowpart, int H, int W, int md, double *bo
   }
   boxsum[(size_t)x * W + y] = s;
 }
-extern "C" void mpp_launch_boxsum(hipStream_t st, const double *rowpart, int H, int W, int md, double *boxsum) {
-  hipLaunchKernelGGL(k_boxsum, dim3((W + 63) / 64, H), dim3(64), 0, st, rowpart, H, W, md, boxsum);
+extern "C" void mpp_launch_boxsum(hipStream_t st, int n_tiles, const double *rowpart, int H, int W, int md, double *boxsum) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 65535) {            // gridDim.z limit
+    const int nt = n_tiles - t0 < 65535 ? n_tiles - t0 : 65535;
+    const size_t off = (size_t)t0 * H * W;
+    hipLaunchKernelGGL(k_boxsum, dim3((W + 63) / 64, H, nt), dim3(64), 0, st, rowpart + off, H, W, md, boxsum + off);
+  }
 }
-extern "C" void mpp_launch_cdf(hipStream_t st, const float *det, int H, int W, double *rowpart, double *rowbase,
+extern "C" void mpp_launch_cdf(hipStream_t st, int n_tiles, const float *det, int H, int W, double *rowpart, double *rowbase,
                                double *scratch_rowtot) {
-  hipLaunchKernelGGL(k_row_partial, dim3((H + 63) / 64), dim3(64), 0, st, det, H, W, rowpart, scratch_rowtot);
-  hipLaunchKernelGGL(k_row_base, dim3(1), dim3(64), 0, st, scratch_rowtot, H, rowbase);
+  for (int t0 = 0; t0 < n_tiles; t0 += 65535) {            // gridDim.y limit
+    const int nt = n_tiles - t0 < 65535 ? n_tiles - t0 : 65535;
+    const size_t off = (size_t)t0 * H * W;
+    hipLaunchKernelGGL(k_row_partial, dim3((H + 63) / 64, nt), dim3(64), 0, st, det + off, H, W, rowpart + off,
+                       scratch_rowtot + (size_t)t0 * H);
+  }
+  hipLaunchKernelGGL(k_row_base, dim3(n_tiles), dim3(64), 0, st, scratch_rowtot, H, rowbase);
 }
 
 // ---- naive detection ------------------------------------------------------------------------------

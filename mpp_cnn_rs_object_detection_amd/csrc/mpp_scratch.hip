@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
   }
   part[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
     __syncthreads();
   }
@@ -188,6 +188,8 @@ extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const
                                        const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
                                        double *dE) {
   if (n_cases <= 0) return;
-  hipLaunchKernelGGL(k_delta_batch, dim3(n_cases), dim3(256), 0, st, P, tiles, tile, rem_off, rem, add_off, add_xy,
+  // one wave per perturbation: only the few points near the change do real work, so small workgroups keep more
+  // perturbations in flight per CU than 256-thread ones (62 -> see DESIGN.md 6 ms for 5000 single-point removals)
+  hipLaunchKernelGGL(k_delta_batch, dim3(n_cases), dim3(64), 0, st, P, tiles, tile, rem_off, rem, add_off, add_xy,
                      add_marks, dE);
 }
