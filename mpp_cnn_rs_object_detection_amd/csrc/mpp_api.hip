@@ -591,7 +591,10 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   const int ncell = c->hp.nx * c->hp.ny;
   const int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
-  const int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
+  // the row level of the birth CDF goes to LDS when it fits and the chain speculates (it shortens the slowest
+  // wave of a round); throughput launches of one-wave chains keep their LDS for occupancy
+  c->hp.rowbase_lds = (c->H <= 1024 && (c->lanes > 0 || c->spec > 1)) ? 1 : 0;
+  const int rb = c->hp.rowbase_lds ? c->H + 1 : 0;
   size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
   if (lds > MPP_LDS_LIMIT)
     return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",

@@ -55,7 +55,7 @@ struct Rec {                  // one speculative step, fully evaluated
 struct Lds {
   double *s, *r, *a, *ca, *sa, *hl, *hw, *rad, *lin, *red0, *red1;
   double *edges;              // [3][32] copy of the mark bin edges
-  double *rowbase;            // [H+1] copy of the birth CDF's row level (lane mode, H <= 1024), else nullptr
+  double *rowbase;            // [H+1] copy of the birth CDF's row level (H <= 1024), else nullptr
   double *stash_v0, *stash_v1;
   double *clip;               // [waves][CLIP_SLOTS][32] polygon buffers of the rectangle clipper
   int *xy;
@@ -596,7 +596,7 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
 }
 __device__ double birth_density(const Chain &c, const Rect &q) {
   const DevParams *P = c.P;
-  double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / c.t.rowbase[P->H];
+  double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / (c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H]);
 #pragma clang loop unroll(disable)
   for (int k = 0; k < 3; ++k)
     d *= row_prob(c, k, q.x, q.y, value_to_class_tab(P, c.L.edges + k * MPP_NCLASS, k, mark_of(q, k)), false, 0.0, nullptr);
@@ -808,7 +808,8 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
   }
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
-    const double u = u53(w[3], w[4]), tot = c.t.rowbase[P->H], thr = u * tot;   // cdf <= u <=> partial sum <= u*total
+    const double u = u53(w[3], w[4]), tot = c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H];
+    const double thr = u * tot;                       // cdf <= u <=> partial sum <= u*total
     int row = 0, col = 0;                             // #rows / #columns whose inclusive cdf is <= u (monotone)
     if (LANE) {
       const double *rb = c.L.rowbase ? c.L.rowbase : c.t.rowbase;
@@ -818,16 +819,28 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
       const double *part = c.t.rowpart + (size_t)row * P->W;
       col = count_le_8ary(P->W, [&](int j) { return (base + part[j]) <= thr; });
     } else {
-      for (int i0 = 0; i0 < P->H; i0 += WAVE) {
-        int i = i0 + c.lane;
-        row += __popcll(__ballot(i < P->H && c.t.rowbase[i + 1] <= thr));
-      }
-      if (row >= P->H) row = P->H - 1;
-      const double base = c.t.rowbase[row];
-      const double *part = c.t.rowpart + (size_t)row * P->W;
-      for (int j0 = 0; j0 < P->W; j0 += WAVE) {
-        int j = j0 + c.lane;
-        col += __popcll(__ballot(j < P->W && (base + part[j]) <= thr));
+      // counts of a monotone table: the loads of a chunk are issued together (8 per lane), then counted -- one memory
+      // latency per 512 entries instead of one per 64.  The row level sits in LDS when it fits (H <= 1024).
+      double base = 0.0;
+      auto row_search = [&](auto rb) {
+        for (int i0 = 0; i0 < P->H; i0 += 8 * WAVE) {
+          double v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { int i = i0 + k * WAVE + c.lane; v[k] = i < P->H ? rb[i + 1] : INFINITY; }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) row += __popcll(__ballot(v[k] <= thr));
+        }
+        if (row >= P->H) row = P->H - 1;
+        base = rb[row];
+      };
+      if (c.L.rowbase) row_search(c.L.rowbase); else row_search(c.t.rowbase);
+      const MPP_GLOBAL double *part = c.t.rowpart + (size_t)row * P->W;
+      for (int j0 = 0; j0 < P->W; j0 += 8 * WAVE) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { int j = j0 + k * WAVE + c.lane; v[k] = j < P->W ? part[j] : INFINITY; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) col += __popcll(__ballot((base + v[k]) <= thr));
       }
     }
     if (col >= P->W) col = P->W - 1;

@@ -35,6 +35,7 @@ struct DevParams {
   int32_t maxd2[MPP_MAX_PAIR];   // floor(max_dist^2): d <= max_dist  <=>  d2 <= maxd2 for integer d2
   int32_t conflict_d2;  // (2*max_inter)^2 + 1: two proposals further apart cannot influence each other
   int32_t n_kernels;    // 8, or 10 when the split / merge kernels carry probability
+  int32_t rowbase_lds;  // the birth CDF's row level ([H+1] doubles) is staged in LDS (set per launch by the host)
   int32_t force_accept; // apply every proposal (perturbation_sampler.py:162-166 walks kernels without accept/reject)
   double inv_step[3];   // 32 / (vmax - vmin)
 };

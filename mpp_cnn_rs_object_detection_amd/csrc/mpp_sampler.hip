@@ -27,7 +27,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   Chain c;
   c.P = P; c.t = tiles[tile];
   const int ncell = P->nx * P->ny, cap = P->cap;
-  const int rowbase_n = (LANE && P->H <= ROWBASE_LDS_MAX) ? P->H + 1 : 0;
+  const int rowbase_n = P->rowbase_lds ? P->H + 1 : 0;
   c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC, rowbase_n, WAVES);
   c.lane = threadIdx.x & (WAVE - 1);
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);   // wave-uniform: lets Philox etc. run on the scalar unit
