@@ -35,6 +35,7 @@
 // diagnostic build only: cycles per phase of wave 0, summed over the launch (never in the product build)
 __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_prof3[16];
+__device__ unsigned long long g_prof4[16];
 __device__ unsigned long long g_prof2[16];
 #define PROF_T0() unsigned long long pt_ = clock64()
 #define PROF_ADD(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof_[i] += n_ - pt_; pt_ = n_; } while (0)
@@ -594,12 +595,22 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
   for (int i = 0; i < MPP_NCLASS; ++i) pc = (i == cls) ? v[i] : pc;
   return (double)pc / tot;
 }
-__device__ double birth_density(const Chain &c, const Rect &q) {
+// `coop`: the wave works on ONE proposal (wave mode).  The three mark rows are then handled by lanes 0, 1 and 2 at
+// the same time -- every lane runs the same sequential sums on its own row, so the values are the ones of three
+// calls in a row -- and collected with readlane: one row latency and one pass of arithmetic instead of three.
+__device__ double birth_density(const Chain &c, const Rect &q, bool coop) {
   const DevParams *P = c.P;
   double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / (c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H]);
+  if (coop) {
+    const int kk = c.lane < 2 ? c.lane : 2;
+    const double pl = row_prob(c, kk, q.x, q.y, value_to_class_tab(P, c.L.edges + kk * MPP_NCLASS, kk, mark_of(q, kk)),
+                               false, 0.0, nullptr);
+    d *= readlane_d(pl, 0); d *= readlane_d(pl, 1); d *= readlane_d(pl, 2);
+  } else {
 #pragma clang loop unroll(disable)
-  for (int k = 0; k < 3; ++k)
-    d *= row_prob(c, k, q.x, q.y, value_to_class_tab(P, c.L.edges + k * MPP_NCLASS, k, mark_of(q, k)), false, 0.0, nullptr);
+    for (int k = 0; k < 3; ++k)
+      d *= row_prob(c, k, q.x, q.y, value_to_class_tab(P, c.L.edges + k * MPP_NCLASS, k, mark_of(q, k)), false, 0.0, nullptr);
+  }
   return d * ((double)P->H * (double)P->W * 32768.0);
 }
 // data-driven translation (transform_kernels.py:77-89): draw a pixel of the (2*max_delta+1)^2 window
@@ -848,13 +859,23 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
     // marks, and on the way the birth density of the drawn point (shape_samplers.py:103-108; same operation
     // order as birth_density())
     double d = (double)c.t.det[(size_t)row * P->W + col] / tot;
+    const uint32_t w5 = w[5], w6 = w[6], w7 = w[7];
+    if (LANE) {
 #pragma clang loop unroll(disable)
-    for (int k = 0; k < 3; ++k) {
-      int cls;
-      const uint32_t w5 = w[5], w6 = w[6], w7 = w[7];
-      d *= row_prob(c, k, row, col, 0, true, u32d(k == 0 ? w5 : (k == 1 ? w6 : w7)), &cls);
-      double val = c.L.edges[k * MPP_NCLASS + cls];
-      if (k == 0) r.as = val; else if (k == 1) r.ar = val; else r.aa = val;
+      for (int k = 0; k < 3; ++k) {
+        int cls;
+        d *= row_prob(c, k, row, col, 0, true, u32d(k == 0 ? w5 : (k == 1 ? w6 : w7)), &cls);
+        double val = c.L.edges[k * MPP_NCLASS + cls];
+        if (k == 0) r.as = val; else if (k == 1) r.ar = val; else r.aa = val;
+      }
+    } else {                      // the three rows in lanes 0, 1, 2 at once (see birth_density)
+      const int kk = c.lane < 2 ? c.lane : 2;
+      int cls_l = 0;
+      const double pl = row_prob(c, kk, row, col, 0, true, u32d(kk == 0 ? w5 : (kk == 1 ? w6 : w7)), &cls_l);
+      const int c0 = __builtin_amdgcn_readlane(cls_l, 0), c1 = __builtin_amdgcn_readlane(cls_l, 1),
+                c2 = __builtin_amdgcn_readlane(cls_l, 2);
+      d *= readlane_d(pl, 0); d *= readlane_d(pl, 1); d *= readlane_d(pl, 2);
+      r.as = c.L.edges[c0]; r.ar = c.L.edges[MPP_NCLASS + c1]; r.aa = c.L.edges[2 * MPP_NCLASS + c2];
     }
     r.qf = d * ((double)P->H * (double)P->W * 32768.0);
     *keep = KEEP_QF;
@@ -907,15 +928,15 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &
 
 // n-independent parts of the forward / backward proposal probabilities.  The symmetric Gaussian
 // kernels have qf == qb, which cancels in the Green ratio: their pdf is evaluated only for traces.
-__device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep) {
+__device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep, bool coop) {
   const DevParams *P = c.P;
   if (keep & KEEP_QF) { r.qb = 1.0; return; }
   r.qf = 1.0; r.qb = 1.0;
   Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
   switch (r.kernel) {
-    case MPP_K_DBIRTH: r.qf = birth_density(c, add); break;
+    case MPP_K_DBIRTH: r.qf = birth_density(c, add, coop); break;
     case MPP_K_DDEATH:
-      if (r.has_rem) r.qb = birth_density(c, load_rect(c.L, r.tslot));
+      if (r.has_rem) r.qb = birth_density(c, load_rect(c.L, r.tslot), coop);
       break;
     case MPP_K_GTRANS:
       if (r.has_rem && tracing)
@@ -1012,7 +1033,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
 #endif
   const DevParams *P = c.P;
   const Lds &L = c.L;
-  proposal_densities(c, r, tracing, keep);
+  proposal_densities(c, r, tracing, keep, !LANE);
   EPROF(4);
   r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
   r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;

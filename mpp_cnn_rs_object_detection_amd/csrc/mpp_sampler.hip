@@ -161,6 +161,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           if (e) { r.valid = 0; r.kernel = -2 - e; }
         } else if (!SM && r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
       }
+#ifdef MPP_PROFILE
+      { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0 && r.kernel >= 0 && r.kernel < 8) atomicAdd(&g_prof4[r.kernel], n_ - pt_); }
+#endif
       PROF_ADD(0);
       if (r.valid && r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
       if (SM && r.valid && r.kernel >= MPP_K_SPLIT && r.has_rem) {
@@ -366,6 +369,10 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
 #ifdef MPP_PROFILE
 extern "C" void mpp_debug_read_prof(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+}
+extern "C" void mpp_debug_read_prof4(unsigned long long *out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof4), z, sizeof z);
 }
 extern "C" void mpp_debug_read_prof3(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 16);

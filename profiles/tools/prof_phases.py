@@ -19,5 +19,7 @@ for spec, lanes in ((1, 0), (8, 0), (1, 1), (1, 4)):
     buf2 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof2(buf2, 1)
     print('   evalD parts (setup, cand, slow, stash, combine):', [round(x/100001) for x in list(buf2)[:5]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001, 'zero-area clips/step', buf2[12]/100001)
     buf3 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof3(buf3)
+    buf4 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof4(buf4)
+    print('   draw cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf4[k]/max(1,buf3[8+k])) for k in range(8)])
     print('   evaluate cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf3[k]/max(1,buf3[8+k])) for k in range(8)], 'counts', list(buf3)[8:16])
     print('spec', spec, 'lanes', lanes, 'kernel ms', ctx.last_kernel_ms(), {n: round(x/100001) for n, x in zip(names, v)}, 'sum', round(v.sum()/100001), 'clock64 ticks/step')
