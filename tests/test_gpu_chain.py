@@ -213,3 +213,48 @@ def test_more_changed_neighbours_than_the_stash_holds(spec, lanes):
     gxy, gm = ctx.get_points()
     oxy, om = o.get_points()
     np.testing.assert_array_equal(gxy, oxy)
+
+
+def test_full_size_workload_properties():
+    """BASELINE configs[1] at full size (512 x 512, 200 objects, 100 001 steps): too long for a step-by-step oracle
+    comparison, so size-independent properties -- 8 speculative waves reproduce the one-wave chain, the incrementally
+    maintained energy equals a from-scratch evaluation of the final configuration (by the oracle), the objects are found."""
+    n_steps, seed = 100001, 0
+    finals = []
+    for spec in (1, 8):
+        t, o, ctx = setup_case(512, 200, "legacy", tile_id=0, noise=0.0, spec=spec, cap=1024)
+        ctx.set_schedule(1.0, 0.999, 0.0)
+        ctx.run(n_steps, seed, chain0=0)
+        finals.append(ctx.get_points())
+        if spec == 8:
+            xy, m = finals[-1]
+            o.set_points(xy, m)
+            assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-8)
+            d = np.sqrt(((xy[:, None, :].astype(float) - t.gt_xy[None]) ** 2).sum(-1))
+            assert (d.min(axis=0) <= 2).mean() >= 0.97 and len(xy) <= 206
+            assert ctx.step_index() == n_steps
+    np.testing.assert_array_equal(finals[0][0], finals[1][0])
+    np.testing.assert_array_equal(finals[0][1], finals[1][1])
+
+
+@pytest.mark.parametrize("shape,spec", [((100, 150), 1), ((150, 100), 8), ((33, 470), 8)])
+def test_ragged_tiles_match_the_oracle(shape, spec):
+    """tiles whose sides are not multiples of the 32-px cell (partial last cells) and far from square"""
+    gt_xy, gt_marks = synth.make_gt(max(shape), 40, tile_id=12)
+    keep = (gt_xy[:, 0] < shape[0] - 3) & (gt_xy[:, 1] < shape[1] - 3)
+    det, marks = synth.render_maps(shape, gt_xy[keep], gt_marks[keep], noise=0.1, noise_seed=5)
+    setup, comb, model = model_for("no-calibration")
+    o = oracle.Oracle(shape, det, marks, model, kernels.make_kernels(mappings.default_mappings(), 1.0))
+    xy, mk = o.naive_detection(setup.detection_threshold, 6.0)
+    kd = kernels.make_kernels(mappings.default_mappings(), max(1, len(xy)))
+    o = oracle.Oracle(shape, det, marks, model, kd)
+    o.set_points(xy, mk)
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec)
+    ctx.set_maps(det, marks); ctx.set_model(model, mappings.default_mappings()); ctx.set_kernels(kd); ctx.set_points(0, xy, mk)
+    o.set_temperature(1.5, 0.998, 0.0); ctx.set_schedule(1.5, 0.998, 0.0)
+    oout, oprops = o.run(4000, 21, chain=0, trace=True)
+    gout, gprops = ctx.run(4000, 21, chain0=0, trace_tile=0)
+    compare_traces(gout, gprops, oout, oprops)
+    gxy, gm = ctx.get_points(); oxy, om = o.get_points()
+    np.testing.assert_array_equal(gxy, oxy)
+    np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
