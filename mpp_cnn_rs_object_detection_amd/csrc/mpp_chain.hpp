@@ -111,12 +111,45 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
   return L;
 }
 
+// the pair terms' parameters, read ONCE per launch into registers: inside the non-unrolled loops of eval_delta every
+// P->model.pair[p].field was a scalar load followed by a wait (the chain kernel is built without machine LICM)
+struct PairRegs { int kind, reduce, maxd2, gated; double coef, p0, max_dist; };
 struct Chain {
   const DevParams *P;
   TileRef t;
   Lds L;
   int lane, wave;
+  int np, comb;
+  PairRegs pr0, pr1;
 };
+__device__ __forceinline__ PairRegs load_pair_regs(const DevParams *P, int p) {
+  PairRegs r;
+  const mpp_pair_term &t = P->model.pair[p];
+  r.kind = t.kind; r.reduce = t.reduce; r.maxd2 = P->maxd2[p]; r.gated = t.gated;
+  r.coef = t.coef; r.p0 = t.p[0]; r.max_dist = t.max_dist;
+  return r;
+}
+__device__ __forceinline__ void load_model_regs(Chain &c) {
+  c.np = c.P->model.n_pair; c.comb = c.P->model.combinator;
+  c.pr0 = load_pair_regs(c.P, 0); c.pr1 = load_pair_regs(c.P, 1);
+}
+__device__ __forceinline__ PairRegs pair_regs(const Chain &c, int p) {
+  PairRegs r;
+  const bool z = p == 0;
+  r.kind = z ? c.pr0.kind : c.pr1.kind; r.reduce = z ? c.pr0.reduce : c.pr1.reduce;
+  r.maxd2 = z ? c.pr0.maxd2 : c.pr1.maxd2; r.gated = z ? c.pr0.gated : c.pr1.gated;
+  r.coef = z ? c.pr0.coef : c.pr1.coef; r.p0 = z ? c.pr0.p0 : c.pr1.p0; r.max_dist = z ? c.pr0.max_dist : c.pr1.max_dist;
+  return r;
+}
+__device__ __forceinline__ double pair_part_c(const Chain &c, int gate, double r0, double r1) {
+  double l = 0.0;
+  if (c.np > 0) l += c.pr0.coef * (c.pr0.gated ? (double)gate : 1.0) * r0;
+  if (c.np > 1) l += c.pr1.coef * (c.pr1.gated ? (double)gate : 1.0) * r1;
+  return l;
+}
+__device__ __forceinline__ double finish_energy_c(const Chain &c, double lin) {
+  return c.comb == MPP_C_LOGISTIC ? 2.0 * sigmoid_d(lin) - 1.0 : lin;
+}
 
 __device__ __forceinline__ void wave_lds_fence() {
   // LDS traffic of one wave is executed in order; this only stops the compiler from moving
@@ -293,21 +326,21 @@ __device__ inline double overlap_energy_chain(const Chain &c, const Geo &u, cons
 }
 
 // pair energy of (u, v) when the overlap value has been computed beforehand (eval_delta's uniform clip phase)
-__device__ __forceinline__ double pair_value_pre(const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v, int d2, double ovl) {
+__device__ __forceinline__ double pair_value_pre(const PairRegs &pt, const Geo2 &u, const Geo2 &v, int d2, double ovl) {
   switch (pt.kind) {
     case MPP_P_OVERLAP: return ovl;
-    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
+    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p0 != 0.0 ? 1.0 : 0.0);
     case MPP_P_DIST_LE: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0; }
     case MPP_P_DIST_LT: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0; }
   }
   return 0.0;
 }
 // pair energy of (u, v); d2 = squared centre distance (integer valued)
-__device__ __forceinline__ double pair_value(const Chain &c, const mpp_pair_term &pt, const Geo2 &u, const Geo2 &v,
+__device__ __forceinline__ double pair_value(const Chain &c, const PairRegs &pt, const Geo2 &u, const Geo2 &v,
                                              bool u_first, int d2) {
   switch (pt.kind) {
     case MPP_P_OVERLAP: return overlap_energy_chain(c, u.g, v.g, u_first, u.rad, v.rad, (double)d2);
-    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p[0] != 0.0 ? 1.0 : 0.0);
+    case MPP_P_ALIGN: return 1.0 - fabs(u.g.ca * v.g.ca + u.g.sa * v.g.sa) - (pt.p0 != 0.0 ? 1.0 : 0.0);
     case MPP_P_DIST_LE: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) <= pt.max_dist ? 1.0 : 0.0; }   // (not speculated)
     case MPP_P_DIST_LT: { asm volatile("" : "+v"(d2)); return sqrt((double)d2) < pt.max_dist ? 1.0 : 0.0; }
   }
@@ -321,7 +354,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
                               const Geo2 &ag) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
-  const mpp_pair_term &pt = P->model.pair[p];
+  const PairRegs pt = pair_regs(c, p);
   int ci, cj;
   cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
   double acc = 0.0;
@@ -338,7 +371,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
         if (w == u || w == skip) continue;
         int wxy = L.xy[w];
         int dx = gu.g.x - (wxy & 0xffff), dy = gu.g.y - ((wxy >> 16) & 0xffff), d2 = dx * dx + dy * dy;
-        if (d2 <= P->maxd2[p]) {
+        if (d2 <= pt.maxd2) {
           Geo2 gw = load_geo(L, w);
           bool uf = slot_first(L, u, gu.g, gw.g.x, gw.g.y, L.s[w], L.r[w], L.a[w]);
           acc = reduce2(pt.reduce, acc, pair_value(c, pt, gu, gw, uf, d2));
@@ -347,7 +380,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
     }
   if (has_add) {
     int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y, d2 = dx * dx + dy * dy;
-    if (d2 <= P->maxd2[p]) {
+    if (d2 <= pt.maxd2) {
       bool uf = slot_first(L, u, gu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
       acc = reduce2(pt.reduce, acc, pair_value(c, pt, gu, ag, uf, d2));
     }
@@ -375,7 +408,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
                              int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
-  const int np = P->model.n_pair;
+  const int np = c.np;
   const bool has_rem = rem >= 0;
   DPROF_T0();
   Geo2 gr;
@@ -447,11 +480,12 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     double ovl_r0 = 0.0, ovl_a0 = 0.0, ovl_r1 = 0.0, ovl_a1 = 0.0;
 #pragma clang loop unroll(disable)
     for (int p = 0; p < np; ++p) {
-      if (P->model.pair[p].kind != MPP_P_OVERLAP) continue;
+      const PairRegs pto = pair_regs(c, p);
+      if (pto.kind != MPP_P_OVERLAP) continue;
 #pragma clang loop unroll(disable)
       for (int which = 0; which < 2; ++which) {
         const double ov = p == 0 ? oldv[0] : oldv[1];
-        bool need = active && (which == 0 ? (has_rem && d2r <= P->maxd2[p] && ov != 0.0) : (has_add && d2a <= P->maxd2[p]));
+        bool need = active && (which == 0 ? (has_rem && d2r <= pto.maxd2 && ov != 0.0) : (has_add && d2a <= pto.maxd2));
         const Geo2 gv = which == 0 ? gr : ag;
         const Rect rv = which == 0 ? rr : ar;
         const double B = geo_area(gv.g);
@@ -492,7 +526,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     if (active) {
 #pragma clang loop unroll(disable)
       for (int p = 0; p < np; ++p) {
-        const mpp_pair_term &pt = P->model.pair[p];
+        const PairRegs pt = pair_regs(c, p);
         const double ov = p == 0 ? oldv[0] : oldv[1];
         double nv = ov, v_add = 0.0;
         bool carries = false, got_add = false;
@@ -500,7 +534,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
         // which = 1: against the added point (it may become u's new extremum)
 #pragma clang loop unroll(disable)
         for (int which = 0; which < 2; ++which) {
-          const bool in = which == 0 ? (has_rem && d2r <= P->maxd2[p] && ov != 0.0) : (has_add && d2a <= P->maxd2[p]);
+          const bool in = which == 0 ? (has_rem && d2r <= pt.maxd2 && ov != 0.0) : (has_add && d2a <= pt.maxd2);
           if (!in) continue;
           const Geo2 gv = which == 0 ? gr : ag;
           const double pre = p == 0 ? (which == 0 ? ovl_r0 : ovl_a0) : (which == 0 ? ovl_r1 : ovl_a1);
@@ -529,8 +563,8 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     if (changed) {
       double lin = L.lin[u];
       int gt = L.gate[u];
-      de_acc += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
-                finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
+      de_acc += finish_energy_c(c, lin + pair_part_c(c, gt, newv[0], newv[1])) -
+                finish_energy_c(c, lin + pair_part_c(c, gt, oldv[0], oldv[1]));
       any_changed = true;
       if (apply) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
     }
@@ -558,14 +592,14 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   while (am) {
     int src = __ffsll((long long)am) - 1;
     am &= am - 1;
-    if (np > 0) ra0 = reduce2(P->model.pair[0].reduce, ra0, readlane_d(ra[0], src));
-    if (np > 1) ra1 = reduce2(P->model.pair[1].reduce, ra1, readlane_d(ra[1], src));
+    if (np > 0) ra0 = reduce2(c.pr0.reduce, ra0, readlane_d(ra[0], src));
+    if (np > 1) ra1 = reduce2(c.pr1.reduce, ra1, readlane_d(ra[1], src));
   }
   *ra0_out = ra0; *ra1_out = ra1;
   *n_stash = stash_n;
   double dE = sum_de;
-  if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra0, ra1));
-  if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  if (has_add) dE += finish_energy_c(c, lin_a + pair_part_c(c, gate_a, ra0, ra1));
+  if (has_rem) dE -= finish_energy_c(c, L.lin[rem] + pair_part_c(c, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
   DPROF(4);
   return dE;
 }
@@ -672,7 +706,7 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
                                   double lin_a, int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
-  const int np = P->model.n_pair;
+  const int np = c.np;
   const bool has_rem = rem >= 0;
   DPROF_T0();
   Geo2 gr;
@@ -702,14 +736,14 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
         if (has_add) { int dx = ux - ag.g.x, dy = uy - ag.g.y; d2a = dx * dx + dy * dy; }
         bool touch = false;
         for (int p = 0; p < np; ++p)
-          touch |= (has_rem && d2r <= P->maxd2[p]) || (has_add && d2a <= P->maxd2[p]);
+          touch |= (has_rem && d2r <= pair_regs(c, p).maxd2) || (has_add && d2a <= pair_regs(c, p).maxd2);
         if (!touch) continue;                    // too far to interact with either point
         Geo2 gu = load_geo(L, u);
         double oldv[2] = {L.red0[u], L.red1[u]}, newv[2];
         newv[0] = oldv[0]; newv[1] = oldv[1];
         for (int p = 0; p < np; ++p) {
-          const mpp_pair_term &pt = P->model.pair[p];
-          bool in_r = has_rem && d2r <= P->maxd2[p], in_a = has_add && d2a <= P->maxd2[p];
+          const PairRegs pt = pair_regs(c, p);
+          bool in_r = has_rem && d2r <= pt.maxd2, in_a = has_add && d2a <= pt.maxd2;
           double nv = oldv[p];
           bool slow = false;
           if (in_r && oldv[p] != 0.0) {
@@ -731,8 +765,8 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
         if (newv[0] != oldv[0] || newv[1] != oldv[1]) {
           double lin = L.lin[u];
           int gt = L.gate[u];
-          sum_de += finish_energy(P, lin + pair_part(P, gt, newv[0], newv[1])) -
-                    finish_energy(P, lin + pair_part(P, gt, oldv[0], oldv[1]));
+          sum_de += finish_energy_c(c, lin + pair_part_c(c, gt, newv[0], newv[1])) -
+                    finish_energy_c(c, lin + pair_part_c(c, gt, oldv[0], oldv[1]));
           if (apply) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
           else if (stash_n < STASH) {
             L.stash_slot[ri * STASH + stash_n] = (unsigned short)u;
@@ -747,8 +781,8 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
   *ra0_out = ra[0]; *ra1_out = ra[1];
   *n_stash = stash_n;
   double dE = sum_de;
-  if (has_add) dE += finish_energy(P, lin_a + pair_part(P, gate_a, ra[0], ra[1]));
-  if (has_rem) dE -= finish_energy(P, L.lin[rem] + pair_part(P, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  if (has_add) dE += finish_energy_c(c, lin_a + pair_part_c(c, gate_a, ra[0], ra[1]));
+  if (has_rem) dE -= finish_energy_c(c, L.lin[rem] + pair_part_c(c, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
   DPROF(4);
   return dE;
 }

@@ -26,6 +26,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   const int tile = tile0 + blockIdx.x;
   Chain c;
   c.P = P; c.t = tiles[tile];
+  load_model_regs(c);
   const int ncell = P->nx * P->ny, cap = P->cap;
   const int rowbase_n = P->rowbase_lds ? P->H + 1 : 0;
   c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC, rowbase_n, WAVES);
