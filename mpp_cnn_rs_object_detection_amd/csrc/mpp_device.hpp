@@ -218,20 +218,32 @@ __device__ __forceinline__ const float *mark_row(const DevParams *P, const TileR
   return b + ((size_t)x * P->W + y) * MPP_NCLASS;
 }
 
-// one unit energy term of a rectangle; `edges` = [3][32] table (HBM or LDS copy)
-__device__ inline double unit_value(const DevParams *P, const TileRef &t, const double *edges, const mpp_unit_term &u,
-                                    const Rect &q, const Geo &g) {
+// the score-map values a rectangle's unit terms can ask for: det at its pixel and, per mark, the probability of the
+// mark's class there.  Fetched together (four independent loads, one memory latency) before the terms are evaluated.
+struct MapVals { float det, m0, m1, m2; };
+__device__ __forceinline__ MapVals load_map_vals(const DevParams *P, const TileRef &t, const double *edges, const Rect &q) {
+  const size_t px = (size_t)q.x * P->W + q.y, pix = px * MPP_NCLASS;
+  const int c0 = value_to_class_tab(P, edges, 0, q.s), c1 = value_to_class_tab(P, edges + MPP_NCLASS, 1, q.r),
+            c2 = value_to_class_tab(P, edges + 2 * MPP_NCLASS, 2, q.a);
+  MapVals v;
+  v.det = t.det[px]; v.m0 = t.m[0][pix + c0]; v.m1 = t.m[1][pix + c1]; v.m2 = t.m[2][pix + c2];
+  return v;
+}
+__device__ __forceinline__ float map_mark(const MapVals &v, int k) {
+  const float a = v.m0, b = v.m1, c = v.m2;
+  return k == 0 ? a : (k == 1 ? b : c);
+}
+
+// one unit energy term of a rectangle
+__device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const Geo &g, const MapVals &mv) {
   switch (u.kind) {
     case MPP_U_POSITION: {
-      float e = -2.0f * (t.det[(size_t)q.x * P->W + q.y] - (float)u.p[0]);   // float32, as numpy does
+      float e = -2.0f * (mv.det - (float)u.p[0]);   // float32, as numpy does
       return (double)e;
     }
     case MPP_U_SHAPE_REMAP: {
-      // the three class lookups, loads and sigmoids are independent chains: keep them side by side
-      const size_t pix = ((size_t)q.x * P->W + q.y) * MPP_NCLASS;
-      int c0 = value_to_class_tab(P, edges, 0, q.s), c1 = value_to_class_tab(P, edges + MPP_NCLASS, 1, q.r),
-          c2 = value_to_class_tab(P, edges + 2 * MPP_NCLASS, 2, q.a);
-      double p0 = (double)t.m[0][pix + c0], p1 = (double)t.m[1][pix + c1], p2 = (double)t.m[2][pix + c2];
+      // the three sigmoids are independent chains: keep them side by side
+      double p0 = (double)mv.m0, p1 = (double)mv.m1, p2 = (double)mv.m2;
       double e0 = exp(-(p0 * u.p[0] + u.p[3])), e1 = exp(-(p1 * u.p[1] + u.p[4])), e2 = exp(-(p2 * u.p[2] + u.p[5]));
       double acc = 0.0;
       acc += -2.0 * (1.0 / (1.0 + e0)) + 1.0;
@@ -239,13 +251,9 @@ __device__ inline double unit_value(const DevParams *P, const TileRef &t, const 
       acc += -2.0 * (1.0 / (1.0 + e2)) + 1.0;
       return acc / 3.0;
     }
-    case MPP_U_MARK_NEG: {
-      int k = (int)u.p[0];
-      return -(double)mark_row(P, t, k, q.x, q.y)[value_to_class_tab(P, edges + k * MPP_NCLASS, k, mark_of(q, k))];
-    }
+    case MPP_U_MARK_NEG: return -(double)map_mark(mv, (int)u.p[0]);
     case MPP_U_MARK_REMAP: {
-      int k = (int)u.p[0];
-      double p = (double)mark_row(P, t, k, q.x, q.y)[value_to_class_tab(P, edges + k * MPP_NCLASS, k, mark_of(q, k))];
+      double p = (double)map_mark(mv, (int)u.p[0]);
       return -2.0 * sigmoid_d(p * u.p[1] + u.p[2]) + 1.0;
     }
     case MPP_U_AREA: {
@@ -264,16 +272,17 @@ __device__ inline double unit_value(const DevParams *P, const TileRef &t, const 
 __device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
                                  const Geo &g, double *lin, int *gate, double *vec_or_null) {
   const mpp_model &M = P->model;
+  const MapVals mv = load_map_vals(P, t, edges, q);
   // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
   double vg = 0.0;
   int gt = 1;
   if (M.gate_term >= 0) {
-    vg = unit_value(P, t, edges, M.unit[M.gate_term], q, g);
+    vg = unit_value(M.unit[M.gate_term], q, g, mv);
     gt = (vg <= M.gate_thr) ? 1 : 0;
   }
   double l = M.lin0;
   for (int k = 0; k < M.n_unit; ++k) {
-    double v = (k == M.gate_term) ? vg : unit_value(P, t, edges, M.unit[k], q, g);
+    double v = (k == M.gate_term) ? vg : unit_value(M.unit[k], q, g, mv);
     if (vec_or_null) vec_or_null[k] = v;
     l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
   }
