@@ -1,4 +1,5 @@
-// mpp_sampler.hip -- the RJMCMC chain of one tile, resident in one workgroup's LDS.
+// mpp_chain.hpp -- the RJMCMC chain of one tile, resident in one workgroup's LDS (device code shared by the
+// instantiations of mpp_sampler.hip).
 //
 // Restates (not translates) the reference's inner loop, models/mpp/rjmcmc_sampler/rjmcmc.py:83-164,
 // with its callees energy_graph.py:139-225 (dE), base_kernels.py / transform_kernels.py /
@@ -14,7 +15,8 @@
 //    the dE sum (ballot + readlane, no 64-wide butterflies);
 //  * instead of rebuilding edges twice per step like the reference, each point caches the
 //    max/min reduction of its pair energies; a removal that takes away a point's extremum
-//    triggers a cooperative re-scan of that point's neighbourhood;
+//    is answered by the added value when that is at least as extreme, otherwise by a re-scan of that point's
+//    neighbourhood in its lane; overlap clips run in uniform control flow with the whole wave on one polygon pair;
 //  * a single dependent chain of float64 transcendentals is what a step costs, so their number is
 //    kept minimal (one exp for the accept test, trig reused when the angle does not change, ...);
 //  * SPEC waves evaluate the next SPEC steps of the SAME chain speculatively against the current

@@ -6,9 +6,9 @@
 // LPW > 0 ("lane mode"): lanes 0..LPW-1 of every wave each evaluate their own step.  SPEC steps per round.
 // DIAG = false is the production instantiation: proposals from Philox, nothing recorded (the tape and
 // trace code is compiled out, which also lowers the register need of the hot loop).
-// OCC: minimum waves per SIMD the register allocation must allow.  The hot loop wants ~340 VGPRs, i.e. ONE
-// wave per SIMD; throughput runs over many tiles ask for OCC = 2 (256 VGPRs, a few spills) so that two chains
-// share a SIMD and hide each other's latencies.
+// OCC: minimum waves per SIMD the register allocation must allow (the hot loop needs ~240 VGPRs: two waves per
+// SIMD).  Throughput runs over many one-wave chains ask for OCC = 2 explicitly so that two chains share a SIMD and
+// hide each other's latencies.
 // SM: the instantiation that also knows the split / merge kernels (mpp_split_merge.hpp); the others carry none of it.
 template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
 __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
