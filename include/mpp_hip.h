@@ -179,6 +179,12 @@ int mpp_last_kernel_ms(mpp_ctx *ctx, double *ms);
 int mpp_posnet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *pos_out, double div_w,
                         double div_b, float *det);
 int mpp_shapenet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *logits, float *marks);
+/* epilogue of one convolution of a DoubleConv block (model_parts/unet/unet_parts.py:12-31), in place on the
+ * convolution's output x [planes][hw] (NCHW, plane p = channel p % C; float32 or bfloat16, device pointers):
+ * x <- max(0, x * scale[c] + shift[c]) with scale = gamma / sqrt(var + eps) and
+ * shift = beta + (conv_bias - mean) * scale, i.e. bias + BatchNorm(eval) + ReLU in one pass. */
+int mpp_affine_relu(mpp_ctx *ctx, void *x, int planes, int C, int64_t hw, int elem_bytes, const float *scale,
+                    const float *shift);
 
 /* IoU matrix of convex quadrilaterals for the DOTA task-1 evaluation: a [n][8], b [m][8] (x1 y1 .. x4 y4, either
  * orientation) -> out [n][m] = |A_i n B_j| / (|A_i| + |B_j| - |A_i n B_j|), or -1 where the axis-aligned extents

@@ -18,6 +18,8 @@ extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, con
                                          int n_cases, const int32_t *rem_off, const int32_t *rem,
                                          const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
                                          int stride, double *before, double *after, unsigned char *mask);
+extern "C" int mpp_launch_affine_relu(hipStream_t st, void *x, int planes, int C, size_t hw, int elem_bytes, const float *scale,
+                                      const float *shift);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors);
@@ -675,6 +677,15 @@ extern "C" int mpp_posnet_epilogue(mpp_ctx *c, int H, int W, int ldh, int ldw, c
   if (!c || !pos_out || !det || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");
   HIPCHK(c, hipSetDevice(c->device));
   mpp_launch_posnet_epilogue(c->stream, pos_out, H, W, ldh, ldw, (float)div_w, (float)div_b, det);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+extern "C" int mpp_affine_relu(mpp_ctx *c, void *x, int planes, int C, int64_t hw, int elem_bytes, const float *scale,
+                               const float *shift) {
+  if (!c || !x || !scale || !shift || planes <= 0 || C <= 0 || hw <= 0 || planes % C) return fail(c, -1, "bad affine_relu arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mpp_launch_affine_relu(c->stream, x, planes, C, (size_t)hw, elem_bytes, scale, shift))
+    return fail(c, -1, "affine_relu: element type must be float32 or bfloat16");
   HIPCHK(c, hipGetLastError());
   return 0;
 }

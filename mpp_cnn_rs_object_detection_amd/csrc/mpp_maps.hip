@@ -230,3 +230,74 @@ extern "C" void mpp_launch_shapenet_epilogue(hipStream_t st, const float *logits
   hipLaunchKernelGGL(k_shapenet_epilogue, dim3((W + WAVE - 1) / WAVE, H), dim3(256), 0, st, logits, H, W, ldh, ldw,
                      marks, vec_ok);
 }
+
+// ---- conv epilogue of the U-Nets' DoubleConv blocks ----------------------------------------------------------
+// y = max(0, x * scale[c] + shift[c]) in place on a [planes][hw] tensor (plane p belongs to channel p % C):
+// BatchNorm(eval) folded with the convolution bias, plus the ReLU, in ONE pass over the activation instead of the
+// three (bias add, batch norm, ReLU) PyTorch runs after each MIOpen convolution (unet_parts.py:12-31).
+// 16-byte accesses: 4 floats or 8 bf16 per lane (hw is a multiple of 8: the image is padded to 2^depth).
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {          // round to nearest even, as torch does
+  unsigned int u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__global__ __launch_bounds__(256) void k_affine_relu_f32(float *x, int C, size_t hw, size_t total4, const float *scale,
+                                                         const float *shift) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  const int ch = (int)((i4 * 4 / hw) % (size_t)C);
+  const float s = scale[ch], t = shift[ch];
+  float4 v = ((float4 *)x)[i4];
+  v.x = fmaxf(0.f, v.x * s + t); v.y = fmaxf(0.f, v.y * s + t); v.z = fmaxf(0.f, v.z * s + t); v.w = fmaxf(0.f, v.w * s + t);
+  ((float4 *)x)[i4] = v;
+}
+__global__ __launch_bounds__(256) void k_affine_relu_bf16(unsigned short *x, int C, size_t hw, size_t total8, const float *scale,
+                                                          const float *shift) {
+  const size_t i8 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i8 >= total8) return;
+  const int ch = (int)((i8 * 8 / hw) % (size_t)C);
+  const float s = scale[ch], t = shift[ch];
+  uint4 v = ((uint4 *)x)[i8];
+  unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float lo = fmaxf(0.f, bf16_to_f32((unsigned short)(w[k] & 0xffffu)) * s + t);
+    float hi = fmaxf(0.f, bf16_to_f32((unsigned short)(w[k] >> 16)) * s + t);
+    w[k] = (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  }
+  ((uint4 *)x)[i8] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+// planes whose size is not a multiple of the vector width (the deepest levels of small images): one element per lane
+__global__ __launch_bounds__(256) void k_affine_relu_any(void *x, int C, size_t hw, size_t total, int elem_bytes,
+                                                         const float *scale, const float *shift) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)((i / hw) % (size_t)C);
+  if (elem_bytes == 4) {
+    float *p = (float *)x;
+    p[i] = fmaxf(0.f, p[i] * scale[ch] + shift[ch]);
+  } else {
+    unsigned short *p = (unsigned short *)x;
+    p[i] = f32_to_bf16(fmaxf(0.f, bf16_to_f32(p[i]) * scale[ch] + shift[ch]));
+  }
+}
+extern "C" int mpp_launch_affine_relu(hipStream_t st, void *x, int planes, int C, size_t hw, int elem_bytes, const float *scale,
+                                      const float *shift) {
+  const size_t total = (size_t)planes * hw;
+  if (elem_bytes != 4 && elem_bytes != 2) return -1;
+  if (hw % (16 / elem_bytes) || ((uintptr_t)x & 15)) {
+    hipLaunchKernelGGL(k_affine_relu_any, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, C, hw, total, elem_bytes,
+                       scale, shift);
+    return 0;
+  }
+  if (elem_bytes == 4) {
+    hipLaunchKernelGGL(k_affine_relu_f32, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, st, (float *)x, C, hw,
+                       total / 4, scale, shift);
+  } else {
+    hipLaunchKernelGGL(k_affine_relu_bf16, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, st, (unsigned short *)x, C,
+                       hw, total / 8, scale, shift);
+  }
+  return 0;
+}

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_affine_relu", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -108,6 +108,7 @@ def load_library(path: Optional[str] = None):
         "mpp_last_kernel_ms": (i32, [vp, C.POINTER(dbl)]),
         "mpp_posnet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, dbl, dbl, vp]),
         "mpp_shapenet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+        "mpp_affine_relu": (i32, [vp, vp, i32, i32, i64, i32, vp, vp]),
         "mpp_quad_iou": (i32, [vp, i32, vp, i32, vp, vp, i32]),
         "mpp_philox4x32": (None, [vp, vp, vp]),
         "mpp_abi_version": (i32, []),
@@ -375,6 +376,12 @@ class MppContext:
     def shapenet_epilogue(self, logits, H: int, W: int, marks_out):
         ldh, ldw = int(logits.shape[-2]), int(logits.shape[-1])
         self._check(self._L.mpp_shapenet_epilogue(self._h, H, W, ldh, ldw, _ptr(logits), _ptr(marks_out)))
+
+    def affine_relu(self, x, scale, shift):
+        """x <- max(0, x * scale[c] + shift[c]) in place; x: contiguous NCHW float32 / bfloat16 CUDA tensor"""
+        n, ch = int(x.shape[0]), int(x.shape[1])
+        hw = int(x.shape[2]) * int(x.shape[3])
+        self._check(self._L.mpp_affine_relu(self._h, _ptr(x), n * ch, ch, hw, int(x.element_size()), _ptr(scale), _ptr(shift)))
 
     # -- evaluation --------------------------------------------------------------------------------
     def quad_iou(self, a, b) -> np.ndarray:

@@ -185,6 +185,38 @@ class ScoreMapNets:
         self.div_w, self.div_b = div_clf or (DIV_CLF_W, DIV_CLF_B)
         self.dtype = dtype
         self.ctx = ctx or MppContext(device)
+        self.fused = os.environ.get("MPP_UNET_UNFUSED", "0") != "1"
+        self._fold_cache = {}
+
+    # -- fused inference path: conv (MIOpen) + ONE pass of bias/BatchNorm/ReLU (mpp_affine_relu) per convolution ------
+    def _folded(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        key = id(conv)
+        if key not in self._fold_cache:
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).float()
+            bias = conv.bias.float() if conv.bias is not None else torch.zeros_like(scale)
+            shift = (bn.bias + (bias - bn.running_mean) * scale).float()
+            self._fold_cache[key] = (scale.contiguous(), shift.contiguous())
+        return self._fold_cache[key]
+
+    def _double_conv(self, dc: DoubleConv, x: Tensor) -> Tensor:
+        seq = dc.double_conv
+        for conv, bn in ((seq[0], seq[1]), (seq[3], seq[4])):
+            scale, shift = self._folded(conv, bn)
+            y = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), conv.weight, None)
+            if not y.is_contiguous():
+                y = y.contiguous()
+            self.ctx.affine_relu(y, scale, shift)
+            x = y
+        return x
+
+    def _backbone(self, net: Unet, x: Tensor) -> Tensor:
+        skips = []
+        for i, down in enumerate(net.descending_path):
+            x = self._double_conv(down, x) if i == 0 else self._double_conv(down.maxpool_conv[1], down.maxpool_conv[0](x))
+            skips.append(x)
+        for up, skip in zip(net.ascending_path, skips[::-1][1:]):
+            x = self._double_conv(up.conv, torch.cat([skip, up.up(x).to(skip.dtype)], dim=1))
+        return x
 
     @torch.no_grad()
     def infer(self, image) -> Tuple[Tensor, List[Tensor]]:
@@ -194,9 +226,17 @@ class ScoreMapNets:
         H, W = img.shape[1:]
         padded, _ = pad_before_infer(img, self.pos.backbone.depth)
         x = padded.unsqueeze(0).contiguous(memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
-            pos_out = self.pos(x)
-            logits = self.shp(x)
+            # (small images are launch-bound: there the extra host calls of the fused path cost more than its two
+            # saved passes per convolution bring -- 512x512: 3.5 ms unfused vs 4.4 ms fused; 2048x2048: 45 vs 41 ms)
+            if self.fused and not self.channels_last and padded.shape[1] * padded.shape[2] >= (1 << 20):
+                pos_out = self.pos.final_layer(self._backbone(self.pos.backbone, x.float()))
+                h = self._backbone(self.shp.backbone, x.float())
+                logits = [fl(h) for fl in self.shp.final_layers]
+            else:
+                pos_out = self.pos(x)
+                logits = self.shp(x)
         pos_out = pos_out[0].float().contiguous()
         logits = [t[0].float().contiguous() for t in logits]
         det = torch.empty((H, W), dtype=torch.float32, device=self.device)

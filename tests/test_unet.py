@@ -99,3 +99,37 @@ def test_hip_epilogues_match_torch_float32(nets):
         ref_m = unet.marks_torch([logits.cpu()], H, W)[0]
         np.testing.assert_allclose(m.cpu().numpy(), ref_m.numpy(), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(m.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_conv_epilogue_matches_the_module_path(nets):
+    """mpp_affine_relu (bias + folded BatchNorm + ReLU in one pass) against nn.Sequential(conv, bn, relu), float32 and
+    bf16, vector and odd plane sizes; and the whole fused forward against the module forward on a 1-Mpx image."""
+    import copy
+    from mpp_cnn_rs_object_detection_amd import hip_api
+    pos, shp = nets
+    runner = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0)
+    g = torch.Generator().manual_seed(1)
+    for (C, H, W) in ((32, 64, 64), (64, 6, 7), (256, 3, 5)):
+        x = torch.randn((1, C, H, W), generator=g).cuda()
+        scale = (torch.rand(C, generator=g) + 0.5).cuda()
+        shift = torch.randn(C, generator=g).cuda()
+        ref = torch.relu(x * scale[None, :, None, None] + shift[None, :, None, None])
+        y = x.clone()
+        runner.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        runner.ctx.affine_relu(y, scale, shift)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), ref.cpu().numpy(), rtol=1e-6, atol=1e-6)
+        yb = x.to(torch.bfloat16).clone()
+        refb = torch.relu(yb.float() * scale[None, :, None, None] + shift[None, :, None, None]).to(torch.bfloat16)
+        runner.ctx.affine_relu(yb, scale, shift)
+        torch.cuda.synchronize()
+        assert torch.equal(yb, refb)                              # same float32 arithmetic, same rounding to bf16
+    img = torch.rand((1024, 1024, 3), generator=g)
+    det_f, marks_f = runner.infer(img)                                # >= 1 Mpx: fused path
+    runner.fused = False
+    det_u, marks_u = runner.infer(img)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(det_f.cpu().numpy(), det_u.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    for a, b in zip(marks_f, marks_u):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-4)
