@@ -258,3 +258,29 @@ def test_ragged_tiles_match_the_oracle(shape, spec):
     gxy, gm = ctx.get_points(); oxy, om = o.get_points()
     np.testing.assert_array_equal(gxy, oxy)
     np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("setup_name", ["legacy", "no-calibration"])
+def test_soak_many_seeds_and_densities_against_the_oracle(setup_name):
+    """Untraced production kernel (8 speculative waves) against the oracle over several tiles, densities and seeds:
+    sparse tiles, a crowded one (cells with more than 3 points: the flattened candidate mapping, rescans, clips) and a
+    hot chain with many births and deaths.  Final configurations must agree (centres exactly, marks to 1e-9)."""
+    cases = [(128, 30, 0.1, 1.0, 0.9985, 11), (96, 45, 0.2, 0.6, 0.999, 12), (160, 20, 0.0, 3.0, 0.9995, 13),
+             (64, 16, 0.3, 1.0, 0.998, 14), (256, 120, 0.1, 0.8, 0.9992, 15)]
+    for k, (size, n_obj, noise, T0, alpha, seed) in enumerate(cases):
+        t, o, ctx = setup_case(size, n_obj, setup_name, tile_id=100 + k, noise=noise, spec=8, cap=1024)
+        if k == 1:                                      # crowd the start: every object twice, slightly shifted
+            xy, mk = o.get_points()
+            xy2 = np.clip(xy + np.array([3, 2]), 0, size - 1)
+            o.set_points(np.concatenate([xy, xy2]), np.concatenate([mk, mk]))
+            ctx.set_points(0, np.concatenate([xy, xy2]), np.concatenate([mk, mk]))
+        o.set_temperature(T0, alpha, 0.0)
+        ctx.set_schedule(T0, alpha, 0.0)
+        n_steps = 15000
+        o.run(n_steps, seed, chain=3)
+        ctx.run(n_steps, seed, chain0=3)
+        gxy, gm = ctx.get_points()
+        oxy, om = o.get_points()
+        np.testing.assert_array_equal(gxy, oxy, err_msg=f"case {k}")
+        np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9, err_msg=f"case {k}")
+        assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-8)
