@@ -213,11 +213,55 @@ def sample_multiple_kernel_perturbations(image_data: ImageWMaps, n_samples: int,
     n_iter = int(iter_per_point * len(start))
     seed = int(rng.integers(0, 2 ** 63 - 1))
     results, perts_out = [], []
+    if (aggregate_pert or not return_perturbations) and n_samples > 1 and n_iter > 0:
+        # Only the net effect of each walk is wanted: all walks run as chains s = 0..n_samples-1 of ONE launch over
+        # replicas of the tile (the chains the loop below runs one launch at a time), and the net removals /
+        # additions are read off the final configurations.
+        finals = _walks_batched(image_data, start, n_samples, n_iter, seed, unit, pair, use_split_merge, device)
+        for final, (removed, added) in finals:
+            results.append(EPointsSet(final, image_data.shape, unit, pair, image_data=image_data, _ctx=ctx))
+            perts_out.append(Perturbation(type=DummyKernel, removal=removed, addition=added))
+        return perts_out if return_perturbations else results
     for s in range(n_samples):
         perts, final = _walk(ctx, start, n_iter, seed, chain=s, shape=image_data.shape, mappings=image_data.mappings)
         results.append(EPointsSet(final, image_data.shape, unit, pair, image_data=image_data, _ctx=ctx))
         perts_out.append(aggregate_perturbations(perts) if aggregate_pert else perts)
     return perts_out if return_perturbations else results
+
+
+def _walks_batched(image_data, start, n_samples, n_iter, seed, unit, pair, use_split_merge, device):
+    """-> per chain: (final configuration, (removed start points, added points)); points that end where they started
+    (same five values) count as kept, which is the aggregate's energy-relevant content"""
+    wctx = MppContext(device, point_capacity=max(256, 4 * len(start) + 64), replicas=n_samples)
+    wctx.set_maps(image_data.detection_map, image_data.param_dist_maps)
+    wctx.set_model(E.build_model_desc(unit, pair, None), image_data.mappings)
+    xy = np.array([[p.x, p.y] for p in start], dtype=np.int32).reshape(-1, 2)
+    mk = np.array([[p.size, p.ratio, p.angle] for p in start], dtype=np.float64).reshape(-1, 3)
+    for i in range(n_samples):
+        wctx.set_points(i, xy, mk)
+    wctx.set_kernels(make_kernels(image_data.mappings, intensity=1.0, use_split_merge=use_split_merge),
+                     intensity=np.ones(n_samples))
+    wctx.set_option("force_accept", 1)
+    wctx.set_schedule(1.0, 1.0, 0.0)
+    wctx.run(n_iter, seed, chain0=0)
+    out = []
+    for i in range(n_samples):
+        fxy, fmk = wctx.get_points(i)
+        pool = {}
+        for p in start:
+            pool.setdefault((p.x, p.y, p.size, p.ratio, p.angle), []).append(p)
+        final, added = [], []
+        for (x, y), (sz, ra, an) in zip(fxy.tolist(), fmk.tolist()):
+            same = pool.get((x, y, sz, ra, an))
+            if same:
+                final.append(same.pop(0))
+            else:
+                q = Rectangle(int(x), int(y), size=float(sz), ratio=float(ra), angle=float(an))
+                final.append(q); added.append(q)
+        removed = [p for p in start if any(p is r for r in pool.get((p.x, p.y, p.size, p.ratio, p.angle), []))]
+        out.append((final, (removed, added)))
+    wctx.close()
+    return out
 
 
 def sample_kernel_perturbations(image_data: ImageWMaps, energy_setup, iter_per_point: float, points: EPointsSet,
