@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MPP_SPEC_LANES", "0")),
                     help="lane mode: 4 waves x LANES lanes, one speculative step per lane (0 = one wave per step)")
     ap.add_argument("--tiles-per-gpu", type=int, default=1)
-    ap.add_argument("--cpu-baseline-chains", type=int, default=12)
+    ap.add_argument("--cpu-baseline-chains", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the (untimed) wall-clock-to-convergence chain")
     ap.add_argument("--batched-tiles", type=int, default=0,
