@@ -123,7 +123,8 @@ int mpp_synchronize(mpp_ctx *ctx);
  * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile, "cell_capacity" (points per
  * 32-px cell), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
  * tile t % n_tiles; "force_accept": apply every proposal without the Metropolis test (the kernel random
- * walks of models/mpp/perturbation_sampler.py:152-169) */
+ * walks of models/mpp/perturbation_sampler.py:152-169).  Read-only: "n_chains", "lds_bytes", and the spatial-hash
+ * geometry "grid_nx", "grid_ny", "grid_res" (point_set/point_set.py:58-61) */
 int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);
 int64_t mpp_get_option(mpp_ctx *ctx, const char *name);
 

@@ -199,6 +199,9 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
+  if (!strcmp(name, "grid_nx")) return c->hp.nx;       // spatial hash dimensions (point_set.py:58-61)
+  if (!strcmp(name, "grid_ny")) return c->hp.ny;
+  if (!strcmp(name, "grid_res")) return (long long)c->hp.res;
   if (!strcmp(name, "lds_bytes")) {
     int ncell = c->hp.nx * c->hp.ny;
     int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;

@@ -106,3 +106,16 @@ def test_out_of_bounds_and_missing_point_errors():
     setp(ctx, [(1, 1)])
     with pytest.raises(hip_api.MppError):         # KeyError of energy_point_set.py:88-100
         delta(ctx, rem=[3])
+
+
+def test_spatial_hash_geometry_of_the_reference_test():
+    """test/test_points_set.py:28-40: support (200, 516), interaction radius 32 -> a 7 x 17 grid of 32-px cells"""
+    from mpp_cnn_rs_object_detection_amd import energies as E
+    ctx = hip_api.MppContext(0)
+    ctx.set_maps(np.zeros((200, 516), np.float32), [np.zeros((200, 516, 32), np.float32)] * 3)
+    pair = [E.PairTerm("near", E.P_DIST_LE, max_dist=32.0, reduce=E.REDUCE_MAX)]
+    ctx.set_model(E.build_model_desc([E.UnitTerm("c", E.U_CONST, [1.0])], pair, None), mappings.default_mappings())
+    assert (ctx.get_option("grid_nx"), ctx.get_option("grid_ny"), ctx.get_option("grid_res")) == (7, 17, 32)
+    pair64 = [E.PairTerm("far", E.P_DIST_LE, max_dist=64.0, reduce=E.REDUCE_MAX)]
+    ctx.set_model(E.build_model_desc([E.UnitTerm("c", E.U_CONST, [1.0])], pair64, None), mappings.default_mappings())
+    assert (ctx.get_option("grid_nx"), ctx.get_option("grid_ny"), ctx.get_option("grid_res")) == (4, 9, 64)
