@@ -271,6 +271,25 @@ def make_split_merge_tapes():
               "no-calibration", params, extra=dict(noise=0.15, noise_seed=77 + 7))
 
 
+def make_dota_sample_golden():
+    """The reference's own data fixture data_sample/DOTA_gsd50/val/2781 (272 vehicles of a real parking lot, arrays
+    only) with the rectangles the reference makes of it (models/mpp/data_loaders.py:254-262)."""
+    import pickle
+    from models.mpp.data_loaders import labels_to_rectangles
+    base = "/root/reference/data_sample/DOTA_gsd50/val"
+    with open(os.path.join(base, "annotations", "2781.pkl"), "rb") as f:
+        lab = pickle.load(f)
+    with open(os.path.join(base, "metadata", "2781.json")) as f:
+        meta = json.load(f)
+    rects = labels_to_rectangles(lab, Rectangle.PARAMETERS)
+    out = dict(centers=np.asarray(lab["centers"], dtype=np.int64), parameters=np.asarray(lab["parameters"], dtype=np.float64),
+               difficult=np.asarray(lab["difficult"], dtype=np.int64),
+               categories=np.array([str(c) for c in lab["categories"]]), shape=np.array(meta["shape"][:2]),
+               ref_rects=np.array([rect_row(r) for r in rects], dtype=np.float64))
+    np.savez_compressed(os.path.join(HERE, "dota_2781.npz"), **out)
+    print("wrote dota_2781.npz:", len(rects), "objects, shape", meta["shape"])
+
+
 def make_delta_cases():
     """Aggregated perturbations (lists of additions/removals): dE, E0, E1, papangelou."""
     out = {}
@@ -413,11 +432,13 @@ def make_perturbation_golden():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert"]
+    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert", "dota"]
     if "pert" in what:
         make_perturbation_golden()
     if "tapes" in what:
         make_tapes()
+    if "dota" in what:
+        make_dota_sample_golden()
     if "sm" in what or "tapes" in what:
         make_split_merge_tapes()
     if "delta" in what:
