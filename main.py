@@ -24,7 +24,8 @@ def main():
     parser.add_argument("-c", "--config", help="model config file, or the name of a stored model")
     parser.add_argument("-o", "--overwrite", action="store_true", help="overwrite existing results")
     parser.add_argument("-r", "--resume", action="store_true", help="(training) resume from checkpoint")
-    parser.add_argument("--spec-waves", type=int, default=8, help="speculative waves per chain (1,2,4,8,16)")
+    parser.add_argument("--spec-waves", type=int, default=None,
+                        help="speculative waves per chain (1,2,4,8,16); default: 8 for fewer than 768 tiles per launch, else 1")
     parser.add_argument("--unet", action="store_true", help="compute the score maps with the U-Nets on the GPU "
                                                             "instead of reading NNNN_results.pkl")
     args = parser.parse_args()

@@ -92,7 +92,7 @@ def load_energy_combinator(save_path: str):
 
 class MPPModel:
     def __init__(self, config: Dict, phase: str = "val", overwrite: bool = False, load: bool = False,
-                 dataset: str = None, device: int = 0, nets=None, spec_waves: int = 8):
+                 dataset: str = None, device: int = 0, nets=None, spec_waves: Optional[int] = None):
         assert phase in ["val", "train"]
         self.config = config
         self.save_path = os.path.join(get_model_base_path(), "mpp", config["model_name"])

@@ -59,7 +59,7 @@ class TileBatchSampler:
     """All tiles of an image (or of a batch of images) sampled concurrently on one GPU."""
 
     def __init__(self, tiles: Sequence[ImageWMaps], energy_setup, energy_combinator, device: int = 0,
-                 point_capacity: int = 1024, spec_waves: int = 8, ctx: Optional[MppContext] = None,
+                 point_capacity: int = 1024, spec_waves: Optional[int] = 8, ctx: Optional[MppContext] = None,
                  use_split_merge: bool = False):
         self.use_split_merge = use_split_merge
         shapes = {tuple(t.shape[:2]) for t in tiles}
@@ -71,6 +71,10 @@ class TileBatchSampler:
         self.mappings = tiles[0].mappings
         unit, pair = energy_setup.make_energies(tiles[0])
         self.model = E.build_model_desc(unit, pair, energy_combinator)
+        if spec_waves is None:
+            # few chains: 8 speculative waves per chain shorten each of them; many chains: one wave per chain fills the
+            # GPU better (profiles/r01_batched_sweep.json: 256 chains 80 vs 29 M proposals/s, crossover near 700)
+            spec_waves = 8 if len(tiles) < 768 else 1
         self.ctx = ctx or MppContext(device, point_capacity=point_capacity, spec_waves=spec_waves)
         det0 = tiles[0].detection_map
         if hasattr(det0, "data_ptr"):                 # maps already on the GPU (U-Net epilogue output)
