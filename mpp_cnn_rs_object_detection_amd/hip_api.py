@@ -71,6 +71,18 @@ class MppError(RuntimeError):
 _lib = None
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the SAME sonames (libamdhip64.so.7,
+    libhsa-runtime64.so.1) as the system one libmppgpu.so is linked against.  Whichever is loaded first serves both:
+    with torch first the process has ONE runtime (and device pointers are shared freely); with /opt/rocm's first, torch
+    later stacks its own HIP on the foreign HSA and reports "No HIP GPUs are available".  So torch, when installed, is
+    imported before the library is opened."""
+    try:
+        import torch  # noqa: F401
+    except Exception:                     # torch missing: the sampler itself does not need it
+        pass
+
+
 def load_library(path: Optional[str] = None):
     """Load libmppgpu.so and declare the prototypes.  Raises if it was not built."""
     global _lib
@@ -80,6 +92,7 @@ def load_library(path: Optional[str] = None):
     if not os.path.exists(path):
         raise ImportError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback for the sampler")
+    _torch_runtime_first()
     L = C.CDLL(path)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     protos = {

@@ -238,6 +238,33 @@ class MPPModel:
         scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
         return merged, scores
 
+    def _prefetch_images(self, patch_ids, dataset, subset):
+        """Images with their score maps, one image ahead of the consumer: while the chain kernel of image i runs, a worker
+        thread reads image i+1 and (with ``nets``) runs the two U-Nets and their epilogues on a side stream."""
+        from concurrent.futures import ThreadPoolExecutor
+        side = None
+        if self.nets is not None:
+            import torch
+            side = torch.cuda.Stream(device=self.device)
+
+        def load(pid):
+            if side is None:
+                return load_image_w_maps(pid, dataset=dataset, subset=subset, position_model=self.position_model,
+                                         shape_model=self.shape_model, nets=None)
+            import torch
+            with torch.cuda.stream(side):
+                data = load_image_w_maps(pid, dataset=dataset, subset=subset, position_model=self.position_model,
+                                         shape_model=self.shape_model, nets=self.nets)
+            side.synchronize()
+            return data
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            fut = pool.submit(load, patch_ids[0]) if patch_ids else None
+            for k in range(len(patch_ids)):
+                data = fut.result()
+                fut = pool.submit(load, patch_ids[k + 1]) if k + 1 < len(patch_ids) else None
+                yield data
+
     def infer(self, subset: str, min_confidence: float = 0.1, display_min_confidence: float = 0.5,
               overwrite: bool = True):
         """Reference ``mpp_model.py:202-370`` (figures are not drawn)."""
@@ -248,14 +275,15 @@ class MPPModel:
         tr = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"])
         tr_sv = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"], postfix="-SV")
         id_re = re.compile(r"([0-9]+).*.png")
+        todo = []
         for pf in fetch_data_paths(dataset, subset)["images"]:
             patch_id = int(id_re.match(os.path.split(pf)[1]).group(1))
             out_file = os.path.join(results_dir, f"{patch_id:04}_results.pkl")
             if os.path.exists(out_file) and not overwrite:
                 print(f"{patch_id:04}_results.pkl exists, skipping")
                 continue
-            image_data = load_image_w_maps(patch_id, dataset=dataset, subset=subset, position_model=self.position_model,
-                                           shape_model=self.shape_model, nets=self.nets)
+            todo.append((patch_id, out_file))
+        for (patch_id, out_file), image_data in zip(todo, self._prefetch_images([t[0] for t in todo], dataset, subset)):
             merged, scores = self.infer_image(image_data, rank, world)
             if rank != 0:
                 continue

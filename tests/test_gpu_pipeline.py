@@ -348,3 +348,34 @@ def test_real_parking_lot_layout_from_the_reference_data_sample():
     # chain keeps ~86 % of them and invents none)
     assert found >= 0.8 * len(gt_xy) and len(pts) <= 1.05 * len(gt_xy), (found, len(pts))
     assert len(scores) == len(pts)
+
+
+def test_main_infer_with_the_unets_on_the_gpu(synthetic_dataset):
+    """``main.py -p infer -m mpp --unet``: PosNet + ShapeNet + epilogues + sampler on the GPU, the next image's score
+    maps computed on a side stream while the current one is sampled.  The container has no trained ``model.pt``; the
+    files are written with seeded random weights, so the detections mean nothing -- the path must run, keep the score
+    maps on the device and write well-formed outputs for every image."""
+    import torch
+    from mpp_cnn_rs_object_detection_amd import unet
+    root, _ = synthetic_dataset
+    for k, seed in ((8, 23), (9, 24)):
+        write_image(root, "val", k, seed)
+    torch.manual_seed(0)
+    for kind, name, net in (("posnet", "posvec_dota", unet.PosNet()), ("shapenet", "shape_dota", unet.ShapeNet())):
+        d = root / "models_storage" / kind / name
+        os.makedirs(d, exist_ok=True)
+        torch.save(net.state_dict(), d / "model.pt")
+    cfg = json.load(open(root / "model_configs" / "mpp" / "mpp_hrcM.json"))
+    cfg["inference"]["rjmcmc_params"]["burn_in"] = 2000
+    with open(root / "cfg_unet.json", "w") as f:
+        json.dump(cfg, f)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", "infer", "-m", "mpp", "-c", str(root / "cfg_unet.json"),
+                        "-d", "SYNTH", "-o", "--unet"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = root / "data" / "inference" / "SYNTH" / "val" / "mpp_hrcM"
+    for k in (7, 8, 9):
+        with open(out / f"{k:04}_results.pkl", "rb") as f:
+            res = pickle.load(f)
+        assert len(res["detection_score"]) == len(res["detection_center"]) == len(res["detection_params"])
+    assert len(open(out / "dota" / "imageSet.txt").read().split()) == 3
