@@ -90,6 +90,20 @@ def load_energy_combinator(save_path: str):
     raise FileNotFoundError(js)
 
 
+class _EpochLoader:
+    """What the reference's DataLoader(collate_fn=identity) is to the trainers: iterating it yields one epoch of
+    batches (lists) of freshly drawn random patches."""
+
+    def __init__(self, data, batch_size: int):
+        self.data, self.batch_size = data, batch_size
+
+    def __len__(self):
+        return (len(self.data) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        return iter(self.data.batches(self.batch_size))
+
+
 class MPPModel:
     def __init__(self, config: Dict, phase: str = "val", overwrite: bool = False, load: bool = False,
                  dataset: str = None, device: int = 0, nets=None, spec_waves: Optional[int] = None):
@@ -159,12 +173,8 @@ class MPPModel:
         if mode == "ordering_criterion":
             from .train_ordering_criterion import Logger, train_ordering_criterion
 
-            class _Loader:                        # a fresh epoch of random patches each time it is iterated
-                def __init__(s, data, bs): s.data, s.bs = data, bs
-                def __len__(s): return (len(s.data) + s.bs - 1) // s.bs
-                def __iter__(s): return iter(s.data.batches(s.bs))
             self.energy_model = train_ordering_criterion(
-                train_loader=_Loader(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
+                train_loader=_EpochLoader(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
                 logger=Logger(self.save_path), energy_setup=self.energy_setup, device=self.device,
                 **self.config["ordering_criterion"])
             save_energy_combinator(self.energy_model, self.save_path)
@@ -173,12 +183,8 @@ class MPPModel:
             from .train_integral_criterion import train_integral_criterion
             from .train_ordering_criterion import Logger
 
-            class _Loader2:
-                def __init__(s, data, bs): s.data, s.bs = data, bs
-                def __len__(s): return (len(s.data) + s.bs - 1) // s.bs
-                def __iter__(s): return iter(s.data.batches(s.bs))
             self.energy_model = train_integral_criterion(
-                train_loader=_Loader2(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
+                train_loader=_EpochLoader(self.data, self.batch_size), rng=self.rng, save_dir=self.save_path,
                 logger=Logger(self.save_path), energy_setup=self.energy_setup, device=self.device, **self.config[mode])
             save_energy_combinator(self.energy_model, self.save_path)
             return
