@@ -347,7 +347,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
     __syncthreads();
     err = __builtin_amdgcn_readfirstlane(L.sh[1]);
     done += __builtin_amdgcn_readfirstlane(L.sh[2]);
-    if (SPEC > 1) __syncthreads();
+    // (no third barrier: the next write to L.sh / L.rec[].valid by the commit wave comes after the next round's
+    // barrier, which every wave reaches only after these reads and those at the top of the loop)
     PROF_ADD(3);
   }
 #ifdef MPP_PROFILE
