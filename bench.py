@@ -145,13 +145,14 @@ def main():
     d = np.sqrt(((final_xy[:, None, :] - tiles[0].gt_xy[None]) ** 2).sum(-1)) if len(final_xy) else np.zeros((0, 1))
     matched = int((d.min(axis=0) <= 2).sum()) if len(final_xy) else 0
 
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu_busy = None, None, None
     tj = os.path.join(REPO, "profiles", "latest_traffic.json")
     if os.path.exists(tj):          # PMC passes cannot run inside this timed process; this is the committed rocprofv3
         with open(tj) as f:         # measurement of the same command (profiles/run_profile.sh), per launch
             t = json.load(f)
         if t.get("iters_per_launch") == args.iters and T == 1:
             traffic, traffic_src = t["hbm_bytes_per_launch"], t["source"]
+            valu_busy = t.get("valu_busy_frac_per_simd_of_the_occupied_cu")
 
     result = {
         "metric": "MPP proposals/s per 512x512 tile",
@@ -173,6 +174,8 @@ def main():
             "kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_proposal": bpp,
             "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
+            "occupied_cu_valu_busy_frac": valu_busy,    # SQ_ACTIVE_INST_VALU of the committed PMC pass: how busy the vector
+                                                        # ALUs of that one CU are (the roof this kernel actually sits under)
         },
     }
 
