@@ -102,9 +102,6 @@ __device__ __forceinline__ void geo_corners(const Geo &g, double *px, double *py
 
 // Sutherland-Hodgman: area of (convex quad S) clipped by (convex ccw quad C)
 __device__ inline double clip_area(const double *sx, const double *sy, const double *cx, const double *cy) {
-#ifdef MPP_NOCLIP                     // timing experiment only (wrong areas): no private arrays -> no scratch
-  return 0.5 * (sx[0] * cy[1] - cx[0] * sy[1]);
-#endif
   double ax[8], ay[8], bx[8], by[8];
   int na = 4;
 #pragma unroll
