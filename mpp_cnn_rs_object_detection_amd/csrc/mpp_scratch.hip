@@ -50,6 +50,7 @@ __device__ double point_energy(const DevParams *P, const TileRef &t, int n, cons
   double lin; int gate;
   unit_part(P, t, &P->maps.edges[0][0], u, gu, &lin, &gate, vec_or_null);
   double red[MPP_MAX_PAIR] = {0.0, 0.0};
+  const int mi = (int)ceil(P->max_inter);
   for (int v = 0; v < n + o.n_extra; ++v) {
     Rect q;
     if (v < n) {
@@ -59,7 +60,10 @@ __device__ double point_energy(const DevParams *P, const TileRef &t, int n, cons
       if (v - n == self_extra) continue;
       q.x = o.exy[2 * (v - n)]; q.y = o.exy[2 * (v - n) + 1];
     }
-    double dx = (double)(u.x - q.x), dy = (double)(u.y - q.y);
+    // (integer box test first: with thousands of points almost every candidate is rejected here, without the sqrt)
+    const int ix = u.x - q.x, iy = u.y - q.y;
+    if (ix > mi || ix < -mi || iy > mi || iy < -mi) continue;
+    double dx = (double)ix, dy = (double)iy;
     double d = sqrt(dx * dx + dy * dy);
     if (d > P->max_inter) continue;
     if (v < n) { q.s = t.ps[v]; q.r = t.pr[v]; q.a = t.pa[v]; }
