@@ -835,15 +835,24 @@ __device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex
 #define KEEP_QF 4             // the forward density was computed while drawing (data-driven birth)
 
 // draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
+// w: the step's Philox blocks 0 and 1.  The uniform of the accept test comes from words 6, 7 -- except for the
+// kernels that use all eight words themselves (the two births, split): only they pay for block 2.
 template <bool LANE>
-__device__ void draw_proposal(const Chain &c, const uint32_t w[12], int n, Rec &r, int *keep) {
+__device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
+                              uint64_t step, uint32_t chain) {
   const DevParams *P = c.P;
   double uk = u53(w[0], w[1]);
   int k = 0;
   while (k < P->n_kernels - 1 && P->p_cum[k] <= uk) ++k;
   r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1;
   r.aux0 = r.aux1 = 0.0; r.ax = r.ay = 0; r.as = r.ar = r.aa = 0.0; r.rx = r.ry = 0;
-  r.u_acc = u53(w[10], w[11]);
+  if (k == MPP_K_UBIRTH || k == MPP_K_DBIRTH || k == MPP_K_SPLIT) {
+    uint32_t e[4];
+    philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), 2u, chain, k0, k1, e);
+    r.u_acc = u53(e[2], e[3]);
+  } else {
+    r.u_acc = u53(w[6], w[7]);
+  }
   *keep = 0;
   if (k == MPP_K_UBIRTH) {
     r.has_add = 1;

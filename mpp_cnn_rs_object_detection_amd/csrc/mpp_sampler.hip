@@ -150,12 +150,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           r.valid = 0; r.kernel = -1;
         }
       } else {
-        uint32_t w[12];
+        uint32_t w[8];
         uint64_t s = (uint64_t)(step0 + my);
 #pragma unroll
-        for (uint32_t b = 0; b < 3; ++b)
+        for (uint32_t b = 0; b < 2; ++b)
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
-        draw_proposal<LANE>(c, w, n, r, &keep);
+        draw_proposal<LANE>(c, w, n, r, &keep, k0, k1, s, chain0 + (uint32_t)tile);
         if (SM && r.kernel >= MPP_K_SPLIT) {
           int e = 0;
           sm_draw(c, r, ri, n, w, k0, k1, s, chain0 + (uint32_t)tile, &e);

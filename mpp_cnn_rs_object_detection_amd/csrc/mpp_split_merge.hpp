@@ -123,9 +123,9 @@ __device__ inline int sm_dense_index(const Chain &c, int n, int slot) {
   return idx;
 }
 
-// the rest of draw_proposal() for the two kernels.  w: the step's 12 words; further Philox blocks (3..10) feed the
+// the rest of draw_proposal() for the two kernels.  w: the step's first 8 words; further Philox blocks (3..10) feed the
 // rejection sampling of the split's position delta (split_and_merge_kernels.py:23-31).
-__device__ inline void sm_draw(const Chain &c, Rec &r, int ri, int n, const uint32_t w[12], uint32_t k0, uint32_t k1,
+__device__ inline void sm_draw(const Chain &c, Rec &r, int ri, int n, const uint32_t w[8], uint32_t k0, uint32_t k1,
                                uint64_t step, uint32_t chain, int *err) {
   const DevParams *P = c.P;
   // (draw_proposal() has run its last branch for these kernel ids: clear what that wrote)

@@ -610,9 +610,10 @@ static int merge_neighbours(const orc_ctx *c, int i0, int *out) {
   return n;
 }
 
-/* draw the proposal of step `step` from its 12 random words (split draws further Philox blocks 3.. of the same
- * step for its rejection sampling) */
-static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *pr, const uint32_t key[2],
+/* draw the proposal of step `step` from Philox blocks 0 and 1 of the step (8 words); the accept uniform is words 6, 7
+ * except for the kernels that need all eight (births, split: block 2); split draws further blocks 3.. for its
+ * rejection sampling */
+static void draw_proposal(const orc_ctx *c, const uint32_t w[8], orc_proposal *pr, const uint32_t key[2],
                           uint64_t step, uint32_t chain) {
   memset(pr, 0, sizeof(*pr));
   double uk = u53(w[0], w[1]);
@@ -620,7 +621,13 @@ static void draw_proposal(const orc_ctx *c, const uint32_t w[12], orc_proposal *
   while (k < c->n_active - 1 && c->p_cum[k] <= uk) ++k;  /* Generator.choice: searchsorted(cdf, u, 'right') */
   pr->kernel = k; pr->target = -1; pr->param_id = -1; pr->new_class = -1;
   pr->aux0 = pr->aux1 = 0.0;
-  pr->u_accept = u53(w[10], w[11]);
+  if (k == ORC_K_UBIRTH || k == ORC_K_DBIRTH || k == ORC_K_SPLIT) {   /* these use all eight words themselves */
+    uint32_t e[4], ctr[4] = {(uint32_t)step, (uint32_t)(step >> 32), 2u, chain};
+    orc_philox(ctr, key, e);
+    pr->u_accept = u53(e[2], e[3]);
+  } else {
+    pr->u_accept = u53(w[6], w[7]);
+  }
   int n = c->n;
   if (k == ORC_K_UBIRTH) {               /* shape_samplers.py:136-141 */
     pr->ax = (int32_t)mulhi(w[3], (uint32_t)c->H); pr->ay = (int32_t)mulhi(w[4], (uint32_t)c->W);
@@ -802,9 +809,9 @@ int orc_replay(orc_ctx *c, int n, const orc_proposal *tape, orc_step_out *out) {
 int orc_run(orc_ctx *c, int64_t n_steps, uint64_t seed, uint32_t chain, orc_step_out *out, orc_proposal *props) {
   uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
   for (int64_t i = 0; i < n_steps; ++i) {
-    uint32_t w[12];
+    uint32_t w[8];
     uint64_t s = (uint64_t)c->step;
-    for (uint32_t b = 0; b < 3; ++b) {
+    for (uint32_t b = 0; b < 2; ++b) {
       uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), b, chain};
       orc_philox(ctr, key, w + 4 * b);
     }
