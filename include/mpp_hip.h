@@ -28,6 +28,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only what this header declares is exported */
+#pragma GCC visibility push(default)
 
 #define MPP_MAX_UNIT 8
 #define MPP_MAX_PAIR 2
@@ -197,6 +199,7 @@ int mpp_quad_iou(mpp_ctx *ctx, int n, const double *a, int m, const double *b, d
 void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 int mpp_abi_version(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

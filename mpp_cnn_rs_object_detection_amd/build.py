@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmppgpu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the CPU oracle forms no FMA, and parity of accept decisions is the contract
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibility=hidden", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # The chain kernel is one huge loop body; machine LICM hoists every float64 literal of the inlined exp/log/sincos
 # polynomials into registers that then spill (296 VGPRs + 40 spills -> 258 VGPRs, 2 spills without it).
 EXTRA = {"mpp_sampler.hip": ["-mllvm", "-disable-machine-licm"]}

@@ -369,18 +369,18 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
 }
 
 #ifdef MPP_PROFILE
-extern "C" void mpp_debug_read_prof(unsigned long long *out) {
+extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
 }
-extern "C" void mpp_debug_read_prof4(unsigned long long *out) {
+extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof4(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 16);
   unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof4), z, sizeof z);
 }
-extern "C" void mpp_debug_read_prof3(unsigned long long *out) {
+extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof3(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof3), sizeof(unsigned long long) * 16);
   unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof3), z, sizeof z);
 }
-extern "C" void mpp_debug_read_prof2(unsigned long long *out, int reset) {
+extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof2(unsigned long long *out, int reset) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof2), sizeof(unsigned long long) * 16);
   (void)hipMemcpyFromSymbol(out + 8, HIP_SYMBOL(g_clip_count), sizeof(unsigned long long));
   if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), z, sizeof z);
