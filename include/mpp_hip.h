@@ -189,6 +189,24 @@ int mpp_shapenet_epilogue(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const fl
 int mpp_affine_relu(mpp_ctx *ctx, void *x, int planes, int C, int64_t hw, int elem_bytes, const float *scale,
                     const float *shift);
 
+/* The two epilogues above on channels-last network outputs: pos_out [ldh][ldw][3], logits [ldh][ldw][32], elements
+ * float32 (elem_bytes 4) or bfloat16 (2), device pointers; same arithmetic and outputs (det [H][W], marks [H][W][32]
+ * float32).  A pixel's 32 logits are contiguous here, so the softmax is one coalesced pass with no transpose. */
+int mpp_posnet_epilogue_nhwc(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const void *pos_out, int elem_bytes, double div_w,
+                             double div_b, float *det);
+int mpp_shapenet_epilogue_nhwc(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const void *logits, int elem_bytes, float *marks);
+
+/* Channels-last (NHWC) glue between two convolutions of the U-Nets, ONE pass over the activation (device pointers,
+ * float32 or bfloat16 elements; in_bytes / out_bytes = 4 or 2):
+ *   y [H+2*pad][W+2*pad][C0+C1] <- reflect_pad( f( maxpool2x2( cat(x0 [..][C0], x1 [..][C1]) ) ) )
+ * with f(v) = max(0, v*scale[c] + shift[c]) (bias + BatchNorm(eval) + ReLU folded as in mpp_affine_relu; identity when
+ * scale == shift == NULL), pool != 0: the sources are [2H][2W] and are max-pooled 2x2 (after f), C1 == 0: no concat,
+ * pad = 0 or 1 (reflect, the padding_mode of every 3x3 convolution).  Replaces F.pad(mode="reflect") + BatchNorm2d +
+ * ReLU (model_parts/unet/unet_parts.py:12-31), MaxPool2d(2) (:34-45) and torch.cat([skip, up]) (:48-67).
+ * y == x0 is allowed when pad == pool == C1 == 0 (in-place epilogue). */
+int mpp_nhwc_glue(mpp_ctx *ctx, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad, int pool,
+                  int in_bytes, int out_bytes, const float *scale, const float *shift);
+
 /* IoU matrix of convex quadrilaterals for the DOTA task-1 evaluation: a [n][8], b [m][8] (x1 y1 .. x4 y4, either
  * orientation) -> out [n][m] = |A_i n B_j| / (|A_i| + |B_j| - |A_i n B_j|), or -1 where the axis-aligned extents
  * (inclusive-pixel +1 convention) do not overlap.  Stands in for `polyiou.iou_poly` and the hbb pre-filter of

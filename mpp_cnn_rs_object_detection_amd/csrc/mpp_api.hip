@@ -20,6 +20,12 @@ extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, con
                                          int stride, double *before, double *after, unsigned char *mask);
 extern "C" int mpp_launch_affine_relu(hipStream_t st, void *x, int planes, int C, size_t hw, int elem_bytes, const float *scale,
                                       const float *shift);
+extern "C" int mpp_launch_posnet_epilogue_nhwc(hipStream_t st, const void *out, int elem_bytes, int H, int W, int ldw, float w,
+                                               float b, float *det);
+extern "C" int mpp_launch_shapenet_epilogue_nhwc(hipStream_t st, const void *logits, int elem_bytes, int H, int W, int ldw,
+                                                 float *marks);
+extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad,
+                                    int pool, int in_bytes, int out_bytes, const float *scale, const float *shift);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors);
@@ -96,7 +102,7 @@ static const char *chain_error_text(int e) {
   return "unknown chain error";
 }
 
-extern "C" int mpp_abi_version(void) { return 2; }   // 2: ten kernels (split, merge), mpp_kernels.split_*
+extern "C" int mpp_abi_version(void) { return 3; }   // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -689,6 +695,36 @@ extern "C" int mpp_affine_relu(mpp_ctx *c, void *x, int planes, int C, int64_t h
   HIPCHK(c, hipSetDevice(c->device));
   if (mpp_launch_affine_relu(c->stream, x, planes, C, (size_t)hw, elem_bytes, scale, shift))
     return fail(c, -1, "affine_relu: element type must be float32 or bfloat16");
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+extern "C" int mpp_posnet_epilogue_nhwc(mpp_ctx *c, int H, int W, int ldh, int ldw, const void *pos_out, int elem_bytes, double div_w,
+                                       double div_b, float *det) {
+  if (!c || !pos_out || !det || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mpp_launch_posnet_epilogue_nhwc(c->stream, pos_out, elem_bytes, H, W, ldw, (float)div_w, (float)div_b, det))
+    return fail(c, -1, "posnet_epilogue_nhwc: element type must be float32 or bfloat16");
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+extern "C" int mpp_shapenet_epilogue_nhwc(mpp_ctx *c, int H, int W, int ldh, int ldw, const void *logits, int elem_bytes, float *marks) {
+  if (!c || !logits || !marks || H <= 0 || W <= 0 || ldh < H || ldw < W) return fail(c, -1, "bad epilogue arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int e = mpp_launch_shapenet_epilogue_nhwc(c->stream, logits, elem_bytes, H, W, ldw, marks);
+  if (e == -1) return fail(c, -1, "shapenet_epilogue_nhwc: element type must be float32 or bfloat16");
+  if (e == -2) return fail(c, -1, "shapenet_epilogue_nhwc: logits and marks must be 16-byte aligned");
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+extern "C" int mpp_nhwc_glue(mpp_ctx *c, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad, int pool,
+                             int in_bytes, int out_bytes, const float *scale, const float *shift) {
+  if (!c || !x0 || !y || H <= 0 || W <= 0 || C0 <= 0 || C1 < 0 || (C1 > 0 && !x1) || (pad != 0 && pad != 1) || (pad && (H < 2 || W < 2)) ||
+      (scale == nullptr) != (shift == nullptr))
+    return fail(c, -1, "bad nhwc_glue arguments");
+  if (y == x0 && (pad || pool || C1)) return fail(c, -1, "nhwc_glue: in place only without pad / pool / cat");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mpp_launch_nhwc_glue(c->stream, x0, C1 > 0 ? x1 : x0, y, H, W, C0, C1, pad, pool ? 1 : 0, in_bytes, out_bytes, scale, shift))
+    return fail(c, -1, "nhwc_glue: element types must be float32 or bfloat16");
   HIPCHK(c, hipGetLastError());
   return 0;
 }

@@ -301,3 +301,193 @@ extern "C" int mpp_launch_affine_relu(hipStream_t st, void *x, int planes, int C
   }
   return 0;
 }
+
+// ---- channels-last (NHWC) glue of the U-Nets: everything between two convolutions in ONE pass ------------------------
+// y[H+2p][W+2p][C0+C1] <- reflect-pad_p( f( pool( cat(x0, x1) ) ) ),  f(v) = max(0, v * scale[c] + shift[c]) (or the
+// identity when scale is null), pool = 2x2 max-pool of the [2H][2W] sources (or none), cat along the channels.
+// Stands for `F.pad(mode="reflect")` inside Conv2d(padding_mode="reflect") together with the BatchNorm+ReLU before it
+// (unet_parts.py:12-31), MaxPool2d(2) (`:34-45`) and torch.cat([skip, up]) (`:48-67`).  In NHWC one pixel's channels are
+// contiguous, so every lane moves 16 bytes (4 floats / 8 bf16) and both streams are fully coalesced.  HBM-bound.
+template <int EB> struct NhwcVec;
+template <> struct NhwcVec<4> {
+  static constexpr int N = 4;
+  __device__ static void load(const void *p, size_t i, float *v) { float4 t = *(const float4 *)((const float *)p + i); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+  __device__ static void store(void *p, size_t i, const float *v) { *(float4 *)((float *)p + i) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct NhwcVec<2> {
+  static constexpr int N = 8;
+  __device__ static void load(const void *p, size_t i, float *v) {
+    uint4 t = *(const uint4 *)((const unsigned short *)p + i);
+    unsigned int w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = bf16_to_f32((unsigned short)(w[k] & 0xffffu)); v[2 * k + 1] = bf16_to_f32((unsigned short)(w[k] >> 16)); }
+  }
+  __device__ static void store(void *p, size_t i, const float *v) {
+    unsigned int w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (unsigned int)f32_to_bf16(v[2 * k]) | ((unsigned int)f32_to_bf16(v[2 * k + 1]) << 16);
+    *(uint4 *)((unsigned short *)p + i) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+template <int EB>
+__global__ __launch_bounds__(256) void k_nhwc_glue_vec(const void *x0, const void *x1, void *y, int H, int W, int C0, int C1,
+                                                        int pad, int pool, const float *scale, const float *shift, size_t total) {
+  constexpr int N = NhwcVec<EB>::N;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int C = C0 + C1, cv = C / N, Wo = W + 2 * pad;
+  const int c = (int)(i % (size_t)cv) * N;
+  const size_t pix = i / (size_t)cv;
+  const int wo = (int)(pix % (size_t)Wo), ho = (int)(pix / (size_t)Wo);
+  const int h = reflect1(ho - pad, H), w = reflect1(wo - pad, W);
+  const void *src = c < C0 ? x0 : x1;
+  const int Cs = c < C0 ? C0 : C1, cs = c < C0 ? c : c - C0;
+  float s[N], t[N], v[N];
+  if (scale) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) { s[k] = scale[c + k]; t[k] = shift[c + k]; }
+  }
+  if (pool) {
+    const int Ws = 2 * W;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float u[N];
+      NhwcVec<EB>::load(src, ((size_t)(2 * h + (q >> 1)) * Ws + (2 * w + (q & 1))) * Cs + cs, u);
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        float a = scale ? fmaxf(0.f, u[k] * s[k] + t[k]) : u[k];
+        v[k] = q == 0 ? a : fmaxf(v[k], a);
+      }
+    }
+  } else {
+    NhwcVec<EB>::load(src, ((size_t)h * W + w) * Cs + cs, v);
+    if (scale) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) v[k] = fmaxf(0.f, v[k] * s[k] + t[k]);
+    }
+  }
+  NhwcVec<EB>::store(y, i * N, v);
+}
+// any channel count / mixed element types (the 3-channel stem: float32 image in, bfloat16 or float32 out): one element per lane
+__global__ __launch_bounds__(256) void k_nhwc_glue_any(const void *x0, const void *x1, void *y, int H, int W, int C0, int C1,
+                                                        int pad, int pool, int in_bytes, int out_bytes, const float *scale,
+                                                        const float *shift, size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int C = C0 + C1, Wo = W + 2 * pad;
+  const int c = (int)(i % (size_t)C);
+  const size_t pix = i / (size_t)C;
+  const int wo = (int)(pix % (size_t)Wo), ho = (int)(pix / (size_t)Wo);
+  const int h = reflect1(ho - pad, H), w = reflect1(wo - pad, W);
+  const void *src = c < C0 ? x0 : x1;
+  const int Cs = c < C0 ? C0 : C1, cs = c < C0 ? c : c - C0;
+  auto rd = [&](size_t j) -> float { return in_bytes == 4 ? ((const float *)src)[j] : bf16_to_f32(((const unsigned short *)src)[j]); };
+  float v = 0.f;
+  if (pool) {
+    const int Ws = 2 * W;
+    for (int q = 0; q < 4; ++q) {
+      float a = rd(((size_t)(2 * h + (q >> 1)) * Ws + (2 * w + (q & 1))) * Cs + cs);
+      if (scale) a = fmaxf(0.f, a * scale[c] + shift[c]);
+      v = q == 0 ? a : fmaxf(v, a);
+    }
+  } else {
+    v = rd(((size_t)h * W + w) * Cs + cs);
+    if (scale) v = fmaxf(0.f, v * scale[c] + shift[c]);
+  }
+  if (out_bytes == 4) ((float *)y)[i] = v; else ((unsigned short *)y)[i] = f32_to_bf16(v);
+}
+extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad,
+                                    int pool, int in_bytes, int out_bytes, const float *scale, const float *shift) {
+  if ((in_bytes != 4 && in_bytes != 2) || (out_bytes != 4 && out_bytes != 2)) return -1;
+  const int C = C0 + C1;
+  const size_t elems = (size_t)(H + 2 * pad) * (W + 2 * pad) * C;
+  const int n = 16 / in_bytes;
+  const bool aligned = (((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)y) & 15) == 0;
+  if (in_bytes == out_bytes && aligned && C0 % n == 0 && C1 % n == 0) {
+    const size_t total = elems / n;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (in_bytes == 4) hipLaunchKernelGGL(k_nhwc_glue_vec<4>, dim3(grid), dim3(256), 0, st, x0, x1, y, H, W, C0, C1, pad, pool, scale, shift, total);
+    else hipLaunchKernelGGL(k_nhwc_glue_vec<2>, dim3(grid), dim3(256), 0, st, x0, x1, y, H, W, C0, C1, pad, pool, scale, shift, total);
+  } else {
+    hipLaunchKernelGGL(k_nhwc_glue_any, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, x0, x1, y, H, W, C0, C1, pad, pool,
+                       in_bytes, out_bytes, scale, shift, elems);
+  }
+  return 0;
+}
+
+// ---- the two epilogues on channels-last network outputs (float32 or bfloat16) ----------------------------------------
+// Same arithmetic, in the same order, as k_posnet_epilogue / k_shapenet_epilogue; only the addressing differs:
+// out [ldh][ldw][3] and logits [ldh][ldw][32].  A pixel's 32 logits are contiguous, so the softmax needs no transpose:
+// 4 lanes per pixel, 8 classes each (one or two 16-byte loads), two 16-byte stores.
+template <int EB> __device__ __forceinline__ float ld_elem(const void *p, size_t i) {
+  return EB == 4 ? ((const float *)p)[i] : bf16_to_f32(((const unsigned short *)p)[i]);
+}
+template <int EB>
+__global__ __launch_bounds__(256) void k_posnet_epilogue_nhwc(const void *out, int H, int W, int ldw, float w, float b, float *det) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x, x = blockIdx.y;
+  if (y >= W || x >= H) return;
+  auto at = [&](int i, int j, int ch) -> float { return ld_elem<EB>(out, ((size_t)i * ldw + j) * 3 + ch); };
+  float g0, g1;
+  if (H == 1) g0 = 0.f;
+  else if (x == 0) g0 = at(1, y, 0) - at(0, y, 0);
+  else if (x == H - 1) g0 = at(x, y, 0) - at(x - 1, y, 0);
+  else g0 = (at(x + 1, y, 0) - at(x - 1, y, 0)) / 2.0f;
+  if (W == 1) g1 = 0.f;
+  else if (y == 0) g1 = at(x, 1, 1) - at(x, 0, 1);
+  else if (y == W - 1) g1 = at(x, y, 1) - at(x, y - 1, 1);
+  else g1 = (at(x, y + 1, 1) - at(x, y - 1, 1)) / 2.0f;
+  float mask = 1.0f / (1.0f + expf(-at(x, y, 2)));
+  float score = w * ((g0 + g1) * mask) + b;
+  det[(size_t)x * W + y] = 1.0f / (1.0f + expf(-score));
+}
+template <int EB>
+__global__ __launch_bounds__(256) void k_shapenet_epilogue_nhwc(const void *logits, int H, int W, int ldw, float *marks) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t pix = t >> 2;
+  const int q = (int)(t & 3);
+  const bool live = pix < (size_t)H * W;           // the 4 lanes of a pixel are live together; dead lanes still shuffle
+  const int x = live ? (int)(pix / (size_t)W) : 0, y = live ? (int)(pix % (size_t)W) : 0;
+  const size_t src = ((size_t)x * ldw + y) * MPP_NCLASS + q * 8;
+  float v[8], m = -INFINITY;
+  if (EB == 4) {
+    const float4 a = *(const float4 *)((const float *)logits + src), c = *(const float4 *)((const float *)logits + src + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  } else {
+    const uint4 a = *(const uint4 *)((const unsigned short *)logits + src);
+    const unsigned int wd[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[2 * k] = bf16_to_f32((unsigned short)(wd[k] & 0xffffu)); v[2 * k + 1] = bf16_to_f32((unsigned short)(wd[k] >> 16)); }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) m = fmaxf(m, v[i]);
+  m = fmaxf(m, __shfl_xor(m, 1, WAVE)); m = fmaxf(m, __shfl_xor(m, 2, WAVE));
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
+  s += __shfl_xor(s, 1, WAVE); s += __shfl_xor(s, 2, WAVE);
+  if (live) {
+    float4 *dst = (float4 *)(marks + pix * MPP_NCLASS + q * 8);
+    dst[0] = make_float4(v[0] / s, v[1] / s, v[2] / s, v[3] / s);
+    dst[1] = make_float4(v[4] / s, v[5] / s, v[6] / s, v[7] / s);
+  }
+}
+extern "C" int mpp_launch_posnet_epilogue_nhwc(hipStream_t st, const void *out, int elem_bytes, int H, int W, int ldw, float w,
+                                               float b, float *det) {
+  const dim3 grid((W + 255) / 256, H);
+  if (elem_bytes == 4) hipLaunchKernelGGL(k_posnet_epilogue_nhwc<4>, grid, dim3(256), 0, st, out, H, W, ldw, w, b, det);
+  else if (elem_bytes == 2) hipLaunchKernelGGL(k_posnet_epilogue_nhwc<2>, grid, dim3(256), 0, st, out, H, W, ldw, w, b, det);
+  else return -1;
+  return 0;
+}
+extern "C" int mpp_launch_shapenet_epilogue_nhwc(hipStream_t st, const void *logits, int elem_bytes, int H, int W, int ldw,
+                                                 float *marks) {
+  if (((uintptr_t)logits & 15) || ((uintptr_t)marks & 15)) return -2;
+  const size_t threads = (size_t)H * W * 4;
+  const unsigned grid = (unsigned)((threads + 255) / 256);
+  if (elem_bytes == 4) hipLaunchKernelGGL(k_shapenet_epilogue_nhwc<4>, dim3(grid), dim3(256), 0, st, logits, H, W, ldw, marks);
+  else if (elem_bytes == 2) hipLaunchKernelGGL(k_shapenet_epilogue_nhwc<2>, dim3(grid), dim3(256), 0, st, logits, H, W, ldw, marks);
+  else return -1;
+  return 0;
+}

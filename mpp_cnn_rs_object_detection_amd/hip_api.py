@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_affine_relu", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -122,6 +122,9 @@ def load_library(path: Optional[str] = None):
         "mpp_posnet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, dbl, dbl, vp]),
         "mpp_shapenet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, vp]),
         "mpp_affine_relu": (i32, [vp, vp, i32, i32, i64, i32, vp, vp]),
+        "mpp_posnet_epilogue_nhwc": (i32, [vp, i32, i32, i32, i32, vp, i32, dbl, dbl, vp]),
+        "mpp_shapenet_epilogue_nhwc": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+        "mpp_nhwc_glue": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
         "mpp_quad_iou": (i32, [vp, i32, vp, i32, vp, vp, i32]),
         "mpp_philox4x32": (None, [vp, vp, vp]),
         "mpp_abi_version": (i32, []),
@@ -390,11 +393,47 @@ class MppContext:
         ldh, ldw = int(logits.shape[-2]), int(logits.shape[-1])
         self._check(self._L.mpp_shapenet_epilogue(self._h, H, W, ldh, ldw, _ptr(logits), _ptr(marks_out)))
 
+    def posnet_epilogue_nhwc(self, pos_out, H: int, W: int, div_w: float, div_b: float, det_out):
+        """``posnet_epilogue`` on a [1,3,Hp,Wp] channels-last (NHWC memory) float32 / bfloat16 network output"""
+        ldh, ldw, ch = nhwc_shape(pos_out)
+        if ch != 3:
+            raise ValueError("posnet output must have 3 channels")
+        self._check(self._L.mpp_posnet_epilogue_nhwc(self._h, H, W, ldh, ldw, _ptr(pos_out), int(pos_out.element_size()),
+                                                     float(div_w), float(div_b), _ptr(det_out)))
+
+    def shapenet_epilogue_nhwc(self, logits, H: int, W: int, marks_out):
+        """``shapenet_epilogue`` on a [1,32,Hp,Wp] channels-last (NHWC memory) float32 / bfloat16 head output"""
+        ldh, ldw, ch = nhwc_shape(logits)
+        if ch != NCLASS:
+            raise ValueError(f"a shapenet head must have {NCLASS} channels")
+        self._check(self._L.mpp_shapenet_epilogue_nhwc(self._h, H, W, ldh, ldw, _ptr(logits), int(logits.element_size()),
+                                                       _ptr(marks_out)))
+
     def affine_relu(self, x, scale, shift):
         """x <- max(0, x * scale[c] + shift[c]) in place; x: contiguous NCHW float32 / bfloat16 CUDA tensor"""
         n, ch = int(x.shape[0]), int(x.shape[1])
         hw = int(x.shape[2]) * int(x.shape[3])
         self._check(self._L.mpp_affine_relu(self._h, _ptr(x), n * ch, ch, hw, int(x.element_size()), _ptr(scale), _ptr(shift)))
+
+    def nhwc_glue(self, x0, x1=None, pad: int = 1, pool: bool = False, scale=None, shift=None, out_dtype=None, out=None):
+        """One pass between two convolutions on channels-last activations (``mpp_nhwc_glue``):
+        reflect_pad(relu(affine(maxpool2(cat(x0, x1))))).  x0 / x1: [1,C,H,W] CUDA tensors with channels_last
+        strides;
+        returns a [1,C0+C1,H',W'] channels_last tensor (``out``: write there, e.g. ``x0`` itself for pad = 0)."""
+        import torch
+        h0, w0, c0 = nhwc_shape(x0)
+        c1 = 0
+        if x1 is not None:
+            h1, w1, c1 = nhwc_shape(x1)
+            if (h1, w1) != (h0, w0) or x1.dtype != x0.dtype:
+                raise ValueError("nhwc_glue: the two sources differ in size or element type")
+        H, W = (h0 // 2, w0 // 2) if pool else (h0, w0)
+        if out is None:
+            out = torch.empty((1, H + 2 * pad, W + 2 * pad, c0 + c1), dtype=out_dtype or x0.dtype, device=x0.device)
+            out = out.permute(0, 3, 1, 2)
+        self._check(self._L.mpp_nhwc_glue(self._h, _ptr(x0), _ptr(x1), _ptr(out), H, W, c0, c1, pad, 1 if pool else 0,
+                                          int(x0.element_size()), int(out.element_size()), _ptr(scale), _ptr(shift)))
+        return out
 
     # -- evaluation --------------------------------------------------------------------------------
     def quad_iou(self, a, b) -> np.ndarray:
@@ -404,6 +443,14 @@ class MppContext:
         out = np.zeros((len(a), len(b)), np.float64)
         self._check(self._L.mpp_quad_iou(self._h, len(a), _ptr(a), len(b), _ptr(b), _ptr(out), 0))
         return out
+
+
+def nhwc_shape(x):
+    """(H, W, C) of a [1,C,H,W] tensor whose memory is NHWC (channels_last strides); raises otherwise."""
+    import torch
+    if x.dim() != 4 or x.shape[0] != 1 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("expected a [1,C,H,W] tensor in channels_last memory format")
+    return int(x.shape[2]), int(x.shape[3]), int(x.shape[1])
 
 
 def philox(ctr, key) -> np.ndarray:

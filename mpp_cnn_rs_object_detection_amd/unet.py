@@ -5,11 +5,13 @@ Same architecture and the same ``state_dict`` keys as the reference (``model_par
 user's ``model.pt`` loads unchanged:  3x3 reflect-padded conv + BatchNorm + ReLU twice per level,
 2x2 max-pool down, 2x2 stride-2 transposed conv up, skip concat ``[skip, up]``, 1x1 heads.
 
-MI355X use: convolutions go through PyTorch-ROCm (MIOpen -> MFMA), in channels-last layout; the
-post-processing of both nets (sigmoid / divergence / 1x1 classifier / sigmoid, and softmax +
-CHW->HWC) is fused into two hand-written HIP kernels (``csrc/mpp_maps.hip``) whose outputs stay on
-the device in exactly the layout the sampler reads -- the reference's pickle round trip
-(``pos_net_model.py:407-424`` -> ``data_loaders.py:30-71``) disappears.
+MI355X use: convolutions go through PyTorch-ROCm (MIOpen -> MFMA) on channels-last (NHWC) activations; everything
+BETWEEN two convolutions -- reflect padding, BatchNorm + bias + ReLU, 2x2 max-pool, the skip concat, the cast to the
+compute type -- is one hand-written HBM-bound pass (``mpp_nhwc_glue``, ``csrc/mpp_maps.hip``), and the
+post-processing of both nets (sigmoid / divergence / 1x1 classifier / sigmoid, and the softmax over a pixel's 32
+contiguous logits) is fused into two more kernels whose outputs stay on the device in exactly the layout the
+sampler reads -- the reference's pickle round trip (``pos_net_model.py:407-424`` -> ``data_loaders.py:30-71``)
+disappears.
 """
 from __future__ import annotations
 
@@ -173,19 +175,25 @@ class ScoreMapNets:
     """PosNet + ShapeNet inference on one GPU with the fused HIP epilogues."""
 
     def __init__(self, posnet: PosNet, shapenet: ShapeNet, device: int = 0, div_clf: Tuple[float, float] = None,
-                 dtype: torch.dtype = torch.float32, ctx=None):
+                 dtype: torch.dtype = torch.float32, ctx=None, layout: Optional[str] = None):
         from .hip_api import MppContext
         self.device = torch.device("cuda", device)
-        # NCHW by default: F.pad(mode="reflect") only has a contiguous-NCHW kernel, so with channels_last every
-        # 3x3 convolution paid two full layout conversions (55 % of the forward in profiles/r01_unet_ops.txt)
-        self.channels_last = os.environ.get("MPP_UNET_CHANNELS_LAST", "0") == "1"
-        fmt = torch.channels_last if self.channels_last else torch.contiguous_format
-        self.pos = posnet.to(self.device).eval().to(memory_format=fmt)
-        self.shp = shapenet.to(self.device).eval().to(memory_format=fmt)
+        # "nhwc": channels-last activations, everything between two convolutions in one `mpp_nhwc_glue` pass;
+        # "nchw": MIOpen on contiguous NCHW with torch's reflection pad and `mpp_affine_relu`
+        self.layout = layout or os.environ.get("MPP_UNET_LAYOUT", "nhwc")
+        if self.layout not in ("nhwc", "nchw"):
+            raise ValueError("layout must be 'nhwc' or 'nchw'")
+        # (torch's F.pad(mode="reflect") only has a contiguous-NCHW kernel: channels-last *modules* pay two layout
+        # conversions per 3x3 convolution -- 55 % of the forward in the first profile; hence the hand-written glue)
+        self.pos = posnet.to(self.device).eval()
+        self.shp = shapenet.to(self.device).eval()
         self.div_w, self.div_b = div_clf or (DIV_CLF_W, DIV_CLF_B)
         self.dtype = dtype
         self.ctx = ctx or MppContext(device)
         self.fused = os.environ.get("MPP_UNET_UNFUSED", "0") != "1"
+        # below this many pixels the forward is launch-bound and the plain nn.Module path (fewer host calls) is faster:
+        # 512x512 3.4 ms vs 4.8 ms; 2048x2048 41 ms (nchw) / 36 ms (nhwc) float32, 31 / 15 ms bfloat16
+        self.min_fused_pixels = 1 << 20
         self._fold_cache = {}
 
     # -- fused inference path: conv (MIOpen) + ONE pass of bias/BatchNorm/ReLU (mpp_affine_relu) per convolution ------
@@ -209,6 +217,45 @@ class ScoreMapNets:
             x = y
         return x
 
+    # -- channels-last path: pad / pool / concat / BatchNorm / ReLU between two convolutions are ONE HIP pass ------------
+    def _weights(self, mod):
+        """(weight, bias) of a convolution in the compute dtype, channels-last; the 3x3 convolutions' bias lives in the
+        folded shift, so only the transposed convolutions and the 1x1 heads use theirs."""
+        key = (id(mod), self.dtype)
+        if key not in self._fold_cache:
+            w = mod.weight.detach().to(self.dtype).contiguous(memory_format=torch.channels_last)
+            b = mod.bias.detach().to(self.dtype) if mod.bias is not None else None
+            self._fold_cache[key] = (w, b)
+        return self._fold_cache[key]
+
+    @staticmethod
+    def _cl(x: Tensor) -> Tensor:
+        return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
+
+    def _double_conv_nhwc(self, dc: DoubleConv, x0: Tensor, x1: Optional[Tensor] = None, pool: bool = False) -> Tensor:
+        seq = dc.double_conv
+        s1, t1 = self._folded(seq[0], seq[1])
+        s2, t2 = self._folded(seq[3], seq[4])
+        y = self.ctx.nhwc_glue(x0, x1, pad=1, pool=pool, out_dtype=self.dtype)
+        r = self._cl(F.conv2d(y, self._weights(seq[0])[0], None))
+        y = self.ctx.nhwc_glue(r, pad=1, scale=s1, shift=t1)
+        r = self._cl(F.conv2d(y, self._weights(seq[3])[0], None))
+        return self.ctx.nhwc_glue(r, pad=0, scale=s2, shift=t2, out=r)
+
+    def _backbone_nhwc(self, net: Unet, x: Tensor) -> Tensor:
+        skips = []
+        for i, down in enumerate(net.descending_path):
+            x = self._double_conv_nhwc(down if i == 0 else down.maxpool_conv[1], x, pool=i > 0)
+            skips.append(x)
+        for up, skip in zip(net.ascending_path, skips[::-1][1:]):
+            w, b = self._weights(up.up)
+            x = self._double_conv_nhwc(up.conv, skip, self._cl(F.conv_transpose2d(x, w, b, stride=2)))
+        return x
+
+    def _head(self, conv: nn.Conv2d, h: Tensor) -> Tensor:
+        w, b = self._weights(conv)
+        return F.conv2d(h, w, b)
+
     def _backbone(self, net: Unet, x: Tensor) -> Tensor:
         skips = []
         for i, down in enumerate(net.descending_path):
@@ -225,18 +272,34 @@ class ScoreMapNets:
         img = img[..., :3].permute(2, 0, 1).float().to(self.device)
         H, W = img.shape[1:]
         padded, _ = pad_before_infer(img, self.pos.backbone.depth)
-        x = padded.unsqueeze(0).contiguous(memory_format=torch.channels_last if self.channels_last else torch.contiguous_format)
+        x = padded.unsqueeze(0).contiguous()
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        big = padded.shape[1] * padded.shape[2] >= self.min_fused_pixels
+        if self.layout == "nhwc" and self.fused and big and padded.shape[1] >= 16 and padded.shape[2] >= 16:
+            xi = padded.permute(1, 2, 0).contiguous().unsqueeze(0).permute(0, 3, 1, 2)      # [1,3,H,W] over NHWC memory
+            pos_out = self._cl(self._head(self.pos.final_layer, self._backbone_nhwc(self.pos.backbone, xi)))
+            h = self._backbone_nhwc(self.shp.backbone, xi)
+            logits = [self._cl(self._head(fl[0], h)) for fl in self.shp.final_layers]
+            det = torch.empty((H, W), dtype=torch.float32, device=self.device)
+            marks = [torch.empty((H, W, 32), dtype=torch.float32, device=self.device) for _ in range(3)]
+            self.ctx.posnet_epilogue_nhwc(pos_out, H, W, self.div_w, self.div_b, det)
+            for k in range(3):
+                self.ctx.shapenet_epilogue_nhwc(logits[k], H, W, marks[k])
+            self._keep = (pos_out, logits)    # alive until the kernels on this stream have consumed them
+            return det, marks
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             # (small images are launch-bound: there the extra host calls of the fused path cost more than its two
             # saved passes per convolution bring -- 512x512: 3.5 ms unfused vs 4.4 ms fused; 2048x2048: 45 vs 41 ms)
-            if self.fused and not self.channels_last and padded.shape[1] * padded.shape[2] >= (1 << 20):
+            if self.fused and big:
                 pos_out = self.pos.final_layer(self._backbone(self.pos.backbone, x.float()))
                 h = self._backbone(self.shp.backbone, x.float())
                 logits = [fl(h) for fl in self.shp.final_layers]
             else:
                 pos_out = self.pos(x)
                 logits = self.shp(x)
+        return self._epilogues(pos_out, logits, H, W)
+
+    def _epilogues(self, pos_out: Tensor, logits: List[Tensor], H: int, W: int) -> Tuple[Tensor, List[Tensor]]:
         pos_out = pos_out[0].float().contiguous()
         logits = [t[0].float().contiguous() for t in logits]
         det = torch.empty((H, W), dtype=torch.float32, device=self.device)

@@ -16,8 +16,8 @@ res = {}
 torch.manual_seed(0)
 for size in (512, 2048):
     img = torch.rand((size, size, 3))
-    for dtype in (torch.float32, torch.bfloat16):
-        runner = unet.ScoreMapNets(unet.PosNet(), unet.ShapeNet(), device=0, dtype=dtype)
+    for dtype, layout in ((torch.float32, "nhwc"), (torch.bfloat16, "nhwc"), (torch.float32, "nchw"), (torch.bfloat16, "nchw")):
+        runner = unet.ScoreMapNets(unet.PosNet(), unet.ShapeNet(), device=0, dtype=dtype, layout=layout)
         for _ in range(3):
             det, marks = runner.infer(img)
         torch.cuda.synchronize()
@@ -27,7 +27,7 @@ for size in (512, 2048):
             det, marks = runner.infer(img)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        res[f"forward+epilogue {size}x{size} {str(dtype).split('.')[-1]}"] = {
+        res[f"forward+epilogue {size}x{size} {str(dtype).split('.')[-1]} {layout}"] = {
             "ms": dt * 1e3, "Mpx_per_s": size * size / dt / 1e6, "TFLOP_per_s": FLOP_PER_PX * size * size / dt / 1e12}
     # epilogues alone (HBM-bound): bytes = read + write
     H = W = size
@@ -48,4 +48,23 @@ for size in (512, 2048):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         res[f"{name} {size}x{size}"] = {"ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000}
+    # the channels-last glue alone (HBM-bound): bytes = read + write of a 32-channel level
+    for dtype in (torch.float32, torch.bfloat16):
+        eb = 4 if dtype == torch.float32 else 2
+        x = torch.randn((1, H, W, 32), device="cuda").to(dtype).permute(0, 3, 1, 2)
+        sc, sh = torch.rand(32, device="cuda"), torch.rand(32, device="cuda")
+        out = torch.empty((1, H + 2, W + 2, 32), device="cuda", dtype=dtype).permute(0, 3, 1, 2)
+        fn = lambda: runner.ctx.nhwc_glue(x, pad=1, scale=sc, shift=sh, out=out)
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        nbytes = eb * 32 * (H * W + (H + 2) * (W + 2))
+        res[f"nhwc_glue pad+affine+relu 32ch {size}x{size} {str(dtype).split('.')[-1]}"] = {
+            "ms": ms, "GB_per_s": nbytes / ms / 1e6, "frac_of_8TBs": nbytes / ms / 1e6 / 8000}
 print(json.dumps(res, indent=1))

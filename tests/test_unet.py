@@ -108,7 +108,7 @@ def test_fused_conv_epilogue_matches_the_module_path(nets):
     import copy
     from mpp_cnn_rs_object_detection_amd import hip_api
     pos, shp = nets
-    runner = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0)
+    runner = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0, layout="nchw")
     g = torch.Generator().manual_seed(1)
     for (C, H, W) in ((32, 64, 64), (64, 6, 7), (256, 3, 5)):
         x = torch.randn((1, C, H, W), generator=g).cuda()
@@ -133,3 +133,117 @@ def test_fused_conv_epilogue_matches_the_module_path(nets):
     np.testing.assert_allclose(det_f.cpu().numpy(), det_u.cpu().numpy(), rtol=1e-3, atol=1e-4)
     for a, b in zip(marks_f, marks_u):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def _nhwc(x):
+    """[1,C,H,W] values in NHWC memory (what the channels-last path passes around)."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.gpu
+def test_nhwc_glue_matches_torch(nets):
+    """mpp_nhwc_glue = reflect_pad(relu(affine(maxpool(cat)))) in one pass, against the torch ops it replaces
+    (F.pad reflect, BatchNorm folded + ReLU, MaxPool2d(2), torch.cat): same float32 arithmetic, so bit-exact in
+    float32 and in bfloat16; vector and one-element-per-lane kernels; in place; the float32 -> bfloat16 stem."""
+    import copy
+    import torch.nn.functional as F
+    pos, shp = nets
+    ctx = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0).ctx
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        for (C0, C1, H, W) in ((32, 0, 16, 24), (64, 64, 8, 12), (3, 0, 10, 14), (32, 32, 2, 2), (8, 24, 6, 10), (5, 3, 4, 6)):
+            x0 = _nhwc(torch.randn((1, C0, H, W), generator=g).cuda().to(dtype))
+            x1 = _nhwc(torch.randn((1, C1, H, W), generator=g).cuda().to(dtype)) if C1 else None
+            C = C0 + C1
+            scale = (torch.rand(C, generator=g) - 0.3).cuda()           # some negative scales: max-pool must come after f
+            shift = torch.randn(C, generator=g).cuda()
+            cat = torch.cat([x0, x1], dim=1) if C1 else x0
+
+            def f(t):
+                return torch.relu(t.float() * scale[None, :, None, None] + shift[None, :, None, None]).to(dtype)
+
+            cases = [
+                (dict(pad=1), F.pad(cat, (1, 1, 1, 1), mode="reflect")),
+                (dict(pad=1, scale=scale, shift=shift), F.pad(f(cat), (1, 1, 1, 1), mode="reflect")),
+                (dict(pad=0, scale=scale, shift=shift), f(cat)),
+                (dict(pad=0), cat),
+            ]
+            if H >= 4 and W >= 4:
+                cases += [
+                    (dict(pad=1, pool=True), F.pad(F.max_pool2d(cat.float(), 2).to(dtype), (1, 1, 1, 1), mode="reflect")),
+                    (dict(pad=1, pool=True, scale=scale, shift=shift),
+                     F.pad(F.max_pool2d(f(cat).float(), 2).to(dtype), (1, 1, 1, 1), mode="reflect")),
+                ]
+            for kw, ref in cases:
+                y = ctx.nhwc_glue(x0, x1, **kw)
+                torch.cuda.synchronize()
+                assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+                assert torch.equal(y, ref), (dtype, C0, C1, H, W, kw)
+            if not C1:                                                    # in place
+                y = x0.clone(memory_format=torch.preserve_format)
+                out = ctx.nhwc_glue(y, pad=0, scale=scale, shift=shift, out=y)
+                torch.cuda.synchronize()
+                assert out.data_ptr() == y.data_ptr() and torch.equal(y, f(x0))
+    # the stem: float32 image -> bfloat16 padded activation
+    img = _nhwc(torch.rand((1, 3, 12, 20), generator=g).cuda())
+    y = ctx.nhwc_glue(img, pad=1, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(y, F.pad(img, (1, 1, 1, 1), mode="reflect").to(torch.bfloat16))
+    # errors are reported, not swallowed
+    with pytest.raises(Exception):
+        ctx.nhwc_glue(img.contiguous(), pad=1)                            # NCHW memory
+    with pytest.raises(Exception):
+        ctx.nhwc_glue(img, pad=1, out=img)                                # in place with a pad
+
+
+@pytest.mark.gpu
+def test_nhwc_epilogues_equal_the_planar_ones(nets):
+    """Same arithmetic in the same order, only the addressing differs: bit-identical outputs for float32; for bfloat16
+    inputs identical to the planar kernels fed the same (bf16-rounded) values."""
+    import copy
+    pos, shp = nets
+    ctx = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0).ctx
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        for (H, W, Hp, Wp) in ((44, 52, 48, 56), (64, 64, 64, 64), (33, 129, 40, 136), (1, 70, 8, 72), (5, 1, 8, 8)):
+            pos_out = torch.randn((1, 3, Hp, Wp), generator=g).cuda().to(dtype)
+            logits = (3.0 * torch.randn((1, 32, Hp, Wp), generator=g)).cuda().to(dtype)
+            d0, d1 = torch.empty((H, W), device="cuda"), torch.empty((H, W), device="cuda")
+            m0, m1 = torch.empty((H, W, 32), device="cuda"), torch.empty((H, W, 32), device="cuda")
+            ctx.posnet_epilogue(pos_out[0].float().contiguous(), H, W, -10.8, -2.1, d0)
+            ctx.shapenet_epilogue(logits[0].float().contiguous(), H, W, m0)
+            ctx.posnet_epilogue_nhwc(_nhwc(pos_out), H, W, -10.8, -2.1, d1)
+            ctx.shapenet_epilogue_nhwc(_nhwc(logits), H, W, m1)
+            torch.cuda.synchronize()
+            assert torch.equal(d0, d1), (dtype, H, W)
+            assert torch.equal(m0, m1), (dtype, H, W)
+
+
+@pytest.mark.gpu
+def test_channels_last_forward_matches_the_module_path(nets):
+    """The whole channels-last forward (MIOpen NHWC convolutions + mpp_nhwc_glue) against the plain nn.Module forward,
+    float32 within 1e-3 (different convolution algorithms), on a size that needs the 2^depth padding; and the bf16
+    variant within bf16 accuracy of it."""
+    import copy
+    pos, shp = nets
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand((200, 330, 3), generator=g)
+    runner = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0, layout="nhwc")
+    runner.min_fused_pixels = 0                                           # small image, but through the fused path
+    det_c, marks_c = runner.infer(img)
+    runner.fused = False                                                  # nn.Module path
+    det_u, marks_u = runner.infer(img)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(det_c.cpu().numpy(), det_u.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    for a, b in zip(marks_c, marks_u):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    rb = unet.ScoreMapNets(copy.deepcopy(pos), copy.deepcopy(shp), device=0, layout="nhwc", dtype=torch.bfloat16)
+    rb.min_fused_pixels = 0
+    det_b, marks_b = rb.infer(img)
+    torch.cuda.synchronize()
+    assert float((det_b - det_u).abs().max()) < 0.08
+    for a, b in zip(marks_b, marks_u):
+        assert float((a - b).abs().max()) < 0.08
+        np.testing.assert_allclose(a.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
