@@ -125,7 +125,9 @@ int mpp_synchronize(mpp_ctx *ctx);
  * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile, "cell_capacity" (points per
  * 32-px cell), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
  * tile t % n_tiles; "force_accept": apply every proposal without the Metropolis test (the kernel random
- * walks of models/mpp/perturbation_sampler.py:152-169).  Read-only: "n_chains", "lds_bytes", and the spatial-hash
+ * walks of models/mpp/perturbation_sampler.py:152-169); "scratch_grid_min_points" (default 256; 0 = never): configurations of
+ * at least that many points get a candidate grid (PointsSet.get_potential_neighbors, point_set.py:111-145) for
+ * mpp_total_energy / mpp_delta_batch / mpp_delta_vectors / mpp_papangelou instead of a scan of all points.  Read-only: "n_chains", "lds_bytes", and the spatial-hash
  * geometry "grid_nx", "grid_ny", "grid_res" (point_set/point_set.py:58-61) */
 int mpp_set_option(mpp_ctx *ctx, const char *name, int64_t value);
 int64_t mpp_get_option(mpp_ctx *ctx, const char *name);
@@ -142,6 +144,9 @@ int mpp_set_kernels(mpp_ctx *ctx, const mpp_kernels *kernels, const double *inte
 int mpp_set_points(mpp_ctx *ctx, int tile, int n, const int32_t *xy, const double *marks);
 int mpp_get_points(mpp_ctx *ctx, int tile, int cap, int32_t *n, int32_t *xy, double *marks);
 int mpp_count(mpp_ctx *ctx, int tile, int32_t *n);
+/* all tiles at once (the per-tile results `Pool.map` hands back, mpp_model.py:250-262): n[n_tiles]; if xy and marks are
+ * not NULL, xy [n_tiles][cap][2] and marks [n_tiles][cap][3] receive the first min(n[t], cap) points of every tile */
+int mpp_get_points_all(mpp_ctx *ctx, int cap, int32_t *n, int32_t *xy, double *marks);
 /* total_energy(): combined energy and, optionally, [n][n_unit+n_pair] per-point vectors */
 int mpp_total_energy(mpp_ctx *ctx, int tile, double *energy, double *vectors_or_null);
 /* energy_delta(Perturbation) for a batch of perturbations with list removals/additions:

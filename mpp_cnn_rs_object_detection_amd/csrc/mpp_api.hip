@@ -17,7 +17,10 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                          int n_cases, const int32_t *rem_off, const int32_t *rem,
                                          const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
-                                         int stride, double *before, double *after, unsigned char *mask);
+                                         int stride, double *before, double *after, unsigned char *mask,
+                                         const int32_t *grid_start, const int32_t *grid_items);
+extern "C" void mpp_launch_grid_build(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n, int ncell,
+                                      int32_t *start, int32_t *cursor, int32_t *items);
 extern "C" int mpp_launch_affine_relu(hipStream_t st, void *x, int planes, int C, size_t hw, int elem_bytes, const float *scale,
                                       const float *shift);
 extern "C" int mpp_launch_posnet_epilogue_nhwc(hipStream_t st, const void *out, int elem_bytes, int H, int W, int ldw, float w,
@@ -28,11 +31,12 @@ extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *
                                     int pool, int in_bytes, int out_bytes, const float *scale, const float *shift);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
-                                          double *e_pts, double *vectors);
+                                          double *e_pts, double *vectors, const int32_t *grid_start,
+                                          const int32_t *grid_items);
 extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                        int n_cases, const int32_t *rem_off, const int32_t *rem,
                                        const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
-                                       double *dE);
+                                       double *dE, const int32_t *grid_start, const int32_t *grid_items);
 extern "C" void mpp_launch_cdf(hipStream_t st, int n_tiles, const float *det, int H, int W, double *rowpart, double *rowbase,
                                double *scratch_rowtot);
 extern "C" void mpp_launch_boxsum(hipStream_t st, int n_tiles, const double *rowpart, int H, int W, int md, double *boxsum);
@@ -68,6 +72,9 @@ struct mpp_ctx {
   TileRef *d_tiles = nullptr;
   double sched[3] = {1.0, 1.0, 0.0};
   double last_ms = 0.0;
+  // uniform grid over one tile's configuration for the from-scratch energies (built per call; see mpp_scratch.hip)
+  int32_t *g_start = nullptr, *g_cursor = nullptr, *g_items = nullptr;
+  int g_cells = 0, g_cap = 0, grid_min_points = 256;
 };
 
 static int fail(mpp_ctx *c, int code, const char *fmt, ...) {
@@ -90,6 +97,26 @@ static hipError_t dalloc(T **p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (count == 0) count = 1;
   return hipMalloc((void **)p, count * sizeof(T));
+}
+
+// Build the candidate grid of `tile` when its configuration is large enough to pay for four small launches; returns
+// the two device arrays through start / items (nullptr, nullptr: the kernels scan the whole configuration).
+static int scratch_grid(mpp_ctx *c, int tile, int n, const int32_t **start, const int32_t **items) {
+  *start = *items = nullptr;
+  if (c->grid_min_points <= 0 || n < c->grid_min_points) return 0;
+  const int ncell = c->hp.nx * c->hp.ny;
+  if (ncell <= 0) return 0;
+  if (ncell > c->g_cells) {
+    if (dalloc(&c->g_start, (size_t)ncell + 1) != hipSuccess || dalloc(&c->g_cursor, (size_t)ncell) != hipSuccess) return -2;
+    c->g_cells = ncell;
+  }
+  if (n > c->g_cap) {
+    if (dalloc(&c->g_items, (size_t)c->cap) != hipSuccess) return -2;
+    c->g_cap = c->cap;
+  }
+  mpp_launch_grid_build(c->stream, c->dp, c->d_tiles, tile, n, ncell, c->g_start, c->g_cursor, c->g_items);
+  *start = c->g_start; *items = c->g_items;
+  return 0;
 }
 
 static const char *chain_error_text(int e) {
@@ -148,6 +175,9 @@ extern "C" int mpp_destroy(mpp_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_tiles(c);
+  if (c->g_start) (void)hipFree(c->g_start);
+  if (c->g_cursor) (void)hipFree(c->g_cursor);
+  if (c->g_items) (void)hipFree(c->g_items);
   if (c->dp) (void)hipFree(c->dp);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -188,6 +218,10 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     if (c->have_maps) return fail(c, -1, "point_capacity must be set before mpp_set_maps");
     if (v < 1 || v > 65535) return fail(c, -1, "point_capacity out of range");
     c->cap = (int)v;
+  } else if (!strcmp(name, "scratch_grid_min_points")) {
+    // configurations of at least this many points get a candidate grid for the from-scratch energies; 0 = never
+    if (v < 0) return fail(c, -1, "scratch_grid_min_points must be >= 0");
+    c->grid_min_points = (int)v;
   } else if (!strcmp(name, "cell_capacity")) {
     if (v < 1 || v > 32) return fail(c, -1, "cell_capacity must be in 1..32");
     c->cell_cap = (int)v; c->params_dirty = true;
@@ -204,6 +238,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "replicas")) return c->replicas;
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
+  if (!strcmp(name, "scratch_grid_min_points")) return c->grid_min_points;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
   if (!strcmp(name, "grid_nx")) return c->hp.nx;       // spatial hash dimensions (point_set.py:58-61)
   if (!strcmp(name, "grid_ny")) return c->hp.ny;
@@ -450,6 +485,40 @@ extern "C" int mpp_get_points(mpp_ctx *c, int tile, int cap, int32_t *n_out, int
   return 0;
 }
 
+// every tile's configuration with five strided copies instead of six small ones per tile (256 tiles: 32 ms -> <1 ms)
+extern "C" int mpp_get_points_all(mpp_ctx *c, int cap, int32_t *n_out, int32_t *xy, double *marks) {
+  if (!c || c->n_tiles <= 0 || !n_out || cap < 0) return fail(c, -1, "bad get_points_all arguments");
+  const int T = c->n_tiles;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(n_out, c->n, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!xy || !marks || cap == 0) return 0;
+  int m = 0;
+  for (int t = 0; t < T; ++t) m = n_out[t] > m ? n_out[t] : m;
+  m = m < cap ? m : cap;
+  m = m < c->cap ? m : c->cap;
+  if (m <= 0) return 0;
+  std::vector<int32_t> x((size_t)T * m), y((size_t)T * m);
+  std::vector<double> s((size_t)T * m), r((size_t)T * m), a((size_t)T * m);
+  const size_t wi = (size_t)m * sizeof(int32_t), wd = (size_t)m * sizeof(double);
+  const size_t pi = (size_t)c->cap * sizeof(int32_t), pd = (size_t)c->cap * sizeof(double);
+  HIPCHK(c, hipMemcpy2DAsync(x.data(), wi, c->px, pi, wi, T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(y.data(), wi, c->py, pi, wi, T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(s.data(), wd, c->ps, pd, wd, T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(r.data(), wd, c->pr, pd, wd, T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(a.data(), wd, c->pa, pd, wd, T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int t = 0; t < T; ++t) {
+    const int k = n_out[t] < m ? n_out[t] : m;
+    for (int i = 0; i < k; ++i) {
+      const size_t src = (size_t)t * m + i, dst = (size_t)t * cap + i;
+      xy[2 * dst] = x[src]; xy[2 * dst + 1] = y[src];
+      marks[3 * dst] = s[src]; marks[3 * dst + 1] = r[src]; marks[3 * dst + 2] = a[src];
+    }
+  }
+  return 0;
+}
+
 extern "C" int mpp_total_energy(mpp_ctx *c, int tile, double *energy, double *vectors) {
   int rc = check_tile(c, tile);
   if (rc) return rc;
@@ -462,7 +531,9 @@ extern "C" int mpp_total_energy(mpp_ctx *c, int tile, double *energy, double *ve
     double *d_e = nullptr, *d_v = nullptr;
     HIPCHK(c, dalloc(&d_e, (size_t)n));
     if (vectors) HIPCHK(c, dalloc(&d_v, (size_t)n * nt));
-    mpp_launch_point_energies(c->stream, c->dp, c->d_tiles, tile, n, d_e, d_v);
+    const int32_t *gs, *gi;
+    if (scratch_grid(c, tile, n, &gs, &gi)) return fail(c, -2, "no device memory for the candidate grid");
+    mpp_launch_point_energies(c->stream, c->dp, c->d_tiles, tile, n, d_e, d_v, gs, gi);
     std::vector<double> he(n);
     hipError_t e1 = hipMemcpyAsync(he.data(), d_e, n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     hipError_t e2 = hipSuccess;
@@ -499,6 +570,8 @@ static int delta_cases(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off
       if (n + (add_off[i + 1] - add_off[i]) > stride)
         return fail(c, -1, "delta_vectors: stride %d < n + additions of case %d (%d)", stride, i, n + add_off[i + 1] - add_off[i]);
   }
+  const int32_t *gs, *gi;
+  if (scratch_grid(c, tile, n, &gs, &gi)) return fail(c, -2, "no device memory for the candidate grid");
   int32_t *d_ro = nullptr, *d_r = nullptr, *d_ao = nullptr, *d_axy = nullptr;
   double *d_am = nullptr, *d_out = nullptr, *d_b = nullptr, *d_a = nullptr;
   unsigned char *d_m = nullptr;
@@ -517,10 +590,10 @@ static int delta_cases(mpp_ctx *c, int tile, int n_cases, const int32_t *rem_off
   up(d_am, add_marks, 3 * (size_t)n_add * sizeof(double));
   if (e == hipSuccess) {
     if (dE) {
-      mpp_launch_delta_batch(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, d_out);
+      mpp_launch_delta_batch(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, d_out, gs, gi);
       e = hipMemcpyAsync(dE, d_out, n_cases * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     } else {
-      mpp_launch_delta_vectors(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, stride, d_b, d_a, d_m);
+      mpp_launch_delta_vectors(c->stream, c->dp, c->d_tiles, tile, n_cases, d_ro, d_r, d_ao, d_axy, d_am, stride, d_b, d_a, d_m, gs, gi);
       e = hipMemcpyAsync(before, d_b, rows * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(after, d_a, rows * nt * sizeof(double), hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipMemcpyAsync(mask, d_m, rows, hipMemcpyDeviceToHost, c->stream);

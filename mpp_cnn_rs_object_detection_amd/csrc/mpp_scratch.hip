@@ -4,10 +4,22 @@
 // total_energy(), energy_delta() for perturbations with LISTS of removals/additions (the
 // aggregated perturbations of perturbation_sampler.py:176-211) and papangelou().  They are the
 // callers' side of the hot path (merge_patches, final scoring, weight learning), not the chain
-// itself, so they favour being obviously right: every point's pair reductions are recomputed by
-// a scan over all points.  They double as the independent check of the chain's cached
+// itself, so they favour being obviously right: every point's pair reductions are recomputed from
+// scratch over all points within range.  They double as the independent check of the chain's cached
 // reductions (the reference's debug=True invariants, energy_point_set.py:126-152).
+// Candidates come from a scan of the whole configuration, or -- for configurations of GRID_MIN_POINTS points or more
+// (a merged image: thousands) -- from the cells around the point of a uniform grid built on the device just before
+// the launch (PointsSet.get_potential_neighbors, point_set.py:111-145; the reductions are max / min, so the visiting
+// order does not change a bit of the result).
 #include "mpp_device.hpp"
+
+struct Grid {                 // CSR over the P->nx x P->ny cells of the tile: items[start[c] .. start[c+1]) = slots in cell c
+  const int32_t *start;       // nullptr: no grid, scan all points
+  const int32_t *items;
+};
+__device__ __forceinline__ int grid_coord(const DevParams *P, int x) {
+  return P->res_shift >= 0 ? (x >> P->res_shift) : (x / P->res_int);
+}
 
 struct Overlay {
   int n_excl; const int32_t *excl;          // slots removed
@@ -44,45 +56,110 @@ __device__ double pair_value_rects(const mpp_pair_term &pt, const Rect &u, const
 // energy vector (unit terms then pair reductions) of rectangle u in the state
 // (configuration - excluded + extras); energy_graph.py:108-137
 __device__ double point_energy(const DevParams *P, const TileRef &t, int n, const Rect &u, int self_slot,
-                               int self_extra, const Overlay &o, double *vec_or_null) {
+                               int self_extra, const Overlay &o, double *vec_or_null, const Grid &g) {
   const mpp_model &M = P->model;
   Geo gu = make_geo(u);
   double lin; int gate;
   unit_part(P, t, &P->maps.edges[0][0], u, gu, &lin, &gate, vec_or_null);
   double red[MPP_MAX_PAIR] = {0.0, 0.0};
   const int mi = (int)ceil(P->max_inter);
-  for (int v = 0; v < n + o.n_extra; ++v) {
+  auto visit = [&](int v) {                       // v < n: slot of the configuration, else added rectangle v - n
     Rect q;
     if (v < n) {
-      if (v == self_slot || excluded(o, v)) continue;
+      if (v == self_slot || excluded(o, v)) return;
       q.x = t.px[v]; q.y = t.py[v];
     } else {
-      if (v - n == self_extra) continue;
+      if (v - n == self_extra) return;
       q.x = o.exy[2 * (v - n)]; q.y = o.exy[2 * (v - n) + 1];
     }
     // (integer box test first: with thousands of points almost every candidate is rejected here, without the sqrt)
     const int ix = u.x - q.x, iy = u.y - q.y;
-    if (ix > mi || ix < -mi || iy > mi || iy < -mi) continue;
+    if (ix > mi || ix < -mi || iy > mi || iy < -mi) return;
     double dx = (double)ix, dy = (double)iy;
     double d = sqrt(dx * dx + dy * dy);
-    if (d > P->max_inter) continue;
+    if (d > P->max_inter) return;
     if (v < n) { q.s = t.ps[v]; q.r = t.pr[v]; q.a = t.pa[v]; }
     else { q.s = o.emarks[3 * (v - n)]; q.r = o.emarks[3 * (v - n) + 1]; q.a = o.emarks[3 * (v - n) + 2]; }
     for (int p = 0; p < M.n_pair; ++p)
       if (d <= M.pair[p].max_dist) red[p] = reduce2(M.pair[p].reduce, red[p], pair_value_rects(M.pair[p], u, gu, q, d));
+  };
+  if (g.start) {
+    const int r = (int)ceil(P->max_inter / P->res);
+    const int ci = grid_coord(P, u.x), cj = grid_coord(P, u.y);
+    for (int i = max(ci - r, 0); i <= min(ci + r, P->nx - 1); ++i)
+      for (int j = max(cj - r, 0); j <= min(cj + r, P->ny - 1); ++j) {
+        const int c = j + i * P->ny;
+        for (int k = g.start[c]; k < g.start[c + 1]; ++k) visit(g.items[k]);
+      }
+    for (int e = 0; e < o.n_extra; ++e) visit(n + e);
+  } else {
+    for (int v = 0; v < n + o.n_extra; ++v) visit(v);
   }
   if (vec_or_null) for (int p = 0; p < M.n_pair; ++p) vec_or_null[M.n_unit + p] = red[p];
   return finish_energy(P, lin + pair_part(P, gate, red[0], red[1]));
 }
 
-__global__ void k_point_energies(const DevParams *P, const TileRef *tiles, int tile, double *e_pts, double *vectors) {
+// ---- the grid: count, scan, fill, sort each cell (deterministic order) ------------------------------------------------
+__global__ void k_grid_count(const DevParams *P, const TileRef *tiles, int tile, int32_t *start) {
+  TileRef t = tiles[tile];
+  const int n = *t.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&start[1 + grid_coord(P, t.py[i]) + grid_coord(P, t.px[i]) * P->ny], 1);
+}
+__global__ __launch_bounds__(1024) void k_grid_scan(int32_t *start, int len) {       // inclusive scan in place, one workgroup
+  __shared__ int part[1024];
+  const int per = (len + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, len);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += start[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    int v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (int i = lo; i < hi; ++i) { run += start[i]; start[i] = run; }
+}
+__global__ void k_grid_fill(const DevParams *P, const TileRef *tiles, int tile, const int32_t *start, int32_t *cursor,
+                            int32_t *items) {
+  TileRef t = tiles[tile];
+  const int n = *t.n, i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = grid_coord(P, t.py[i]) + grid_coord(P, t.px[i]) * P->ny;
+  items[start[c] + atomicAdd(&cursor[c], 1)] = i;
+}
+__global__ void k_grid_sort(const int32_t *start, int32_t *items, int ncell) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  const int lo = start[c], hi = start[c + 1];
+  for (int i = lo + 1; i < hi; ++i) {
+    const int v = items[i];
+    int k = i - 1;
+    while (k >= lo && items[k] > v) { items[k + 1] = items[k]; --k; }
+    items[k + 1] = v;
+  }
+}
+// start: [ncell + 1], cursor: [ncell], items: [n]
+extern "C" void mpp_launch_grid_build(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n, int ncell,
+                                      int32_t *start, int32_t *cursor, int32_t *items) {
+  (void)hipMemsetAsync(start, 0, sizeof(int32_t) * ((size_t)ncell + 1), st);
+  (void)hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)ncell, st);
+  const unsigned gb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, P, tiles, tile, start);
+  hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, start, ncell + 1);
+  hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(256), 0, st, P, tiles, tile, (const int32_t *)start, cursor, items);
+  hipLaunchKernelGGL(k_grid_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, (const int32_t *)start, items, ncell);
+}
+
+__global__ void k_point_energies(const DevParams *P, const TileRef *tiles, int tile, double *e_pts, double *vectors, Grid g) {
   TileRef t = tiles[tile];
   int n = *t.n, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Overlay none{0, nullptr, 0, nullptr, nullptr};
   int nt = P->model.n_unit + P->model.n_pair;
   double vec[MPP_MAX_UNIT + MPP_MAX_PAIR];
-  e_pts[i] = point_energy(P, t, n, tile_rect(t, i), i, -1, none, vec);
+  e_pts[i] = point_energy(P, t, n, tile_rect(t, i), i, -1, none, vec, g);
   if (vectors) for (int k = 0; k < nt; ++k) vectors[(size_t)i * nt + k] = vec[k];
 }
 
@@ -90,7 +167,7 @@ __global__ void k_point_energies(const DevParams *P, const TileRef *tiles, int t
 __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const TileRef *tiles, int tile,
                                                      const int32_t *rem_off, const int32_t *rem,
                                                      const int32_t *add_off, const int32_t *add_xy,
-                                                     const double *add_marks, double *dE) {
+                                                     const double *add_marks, double *dE, Grid g) {
   __shared__ double part[256];
   TileRef t = tiles[tile];
   const int n = *t.n, cs = blockIdx.x;
@@ -103,7 +180,7 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
   for (int i = threadIdx.x; i < n + o.n_extra; i += blockDim.x) {
     if (i < n) {
       Rect u = tile_rect(t, i);
-      if (excluded(o, i)) { acc -= point_energy(P, t, n, u, i, -1, none, nullptr); continue; }
+      if (excluded(o, i)) { acc -= point_energy(P, t, n, u, i, -1, none, nullptr, g); continue; }
       bool touched = false;                      // does any changed point interact with u?
       for (int k = 0; k < o.n_excl && !touched; ++k) {
         double dx = (double)(u.x - t.px[o.excl[k]]), dy = (double)(u.y - t.py[o.excl[k]]);
@@ -113,9 +190,9 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
         double dx = (double)(u.x - o.exy[2 * k]), dy = (double)(u.y - o.exy[2 * k + 1]);
         touched = sqrt(dx * dx + dy * dy) <= P->max_inter;
       }
-      if (touched) acc += point_energy(P, t, n, u, i, -1, o, nullptr) - point_energy(P, t, n, u, i, -1, none, nullptr);
+      if (touched) acc += point_energy(P, t, n, u, i, -1, o, nullptr, g) - point_energy(P, t, n, u, i, -1, none, nullptr, g);
     } else {
-      acc += point_energy(P, t, n, extra_rect(o, i - n), -1, i - n, o, nullptr);
+      acc += point_energy(P, t, n, extra_rect(o, i - n), -1, i - n, o, nullptr, g);
     }
   }
   part[threadIdx.x] = acc;
@@ -136,7 +213,7 @@ __global__ __launch_bounds__(256) void k_delta_vectors(const DevParams *P, const
                                                        const int32_t *rem_off, const int32_t *rem,
                                                        const int32_t *add_off, const int32_t *add_xy,
                                                        const double *add_marks, int stride, double *before,
-                                                       double *after, unsigned char *mask) {
+                                                       double *after, unsigned char *mask, Grid g) {
   TileRef t = tiles[tile];
   const int n = *t.n, cs = blockIdx.x;
   const int nt = P->model.n_unit + P->model.n_pair;
@@ -152,7 +229,7 @@ __global__ __launch_bounds__(256) void k_delta_vectors(const DevParams *P, const
     unsigned char mk = 0;
     if (i < n) {
       Rect u = tile_rect(t, i);
-      if (excluded(o, i)) { point_energy(P, t, n, u, i, -1, none, vb); mk = 2; }
+      if (excluded(o, i)) { point_energy(P, t, n, u, i, -1, none, vb, g); mk = 2; }
       else {
         bool touched = false;
         for (int k = 0; k < o.n_excl && !touched; ++k) {
@@ -163,10 +240,10 @@ __global__ __launch_bounds__(256) void k_delta_vectors(const DevParams *P, const
           double dx = (double)(u.x - o.exy[2 * k]), dy = (double)(u.y - o.exy[2 * k + 1]);
           touched = sqrt(dx * dx + dy * dy) <= P->max_inter;
         }
-        if (touched) { point_energy(P, t, n, u, i, -1, none, vb); point_energy(P, t, n, u, i, -1, o, va); mk = 1; }
+        if (touched) { point_energy(P, t, n, u, i, -1, none, vb, g); point_energy(P, t, n, u, i, -1, o, va, g); mk = 1; }
       }
     } else if (i - n < o.n_extra) {
-      point_energy(P, t, n, extra_rect(o, i - n), -1, i - n, o, va);
+      point_energy(P, t, n, extra_rect(o, i - n), -1, i - n, o, va, g);
       mk = 3;
     }
     mask[row] = mk;
@@ -177,23 +254,26 @@ __global__ __launch_bounds__(256) void k_delta_vectors(const DevParams *P, const
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                          int n_cases, const int32_t *rem_off, const int32_t *rem,
                                          const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
-                                         int stride, double *before, double *after, unsigned char *mask) {
+                                         int stride, double *before, double *after, unsigned char *mask,
+                                         const int32_t *grid_start, const int32_t *grid_items) {
   if (n_cases <= 0 || stride <= 0) return;
   hipLaunchKernelGGL(k_delta_vectors, dim3(n_cases), dim3(256), 0, st, P, tiles, tile, rem_off, rem, add_off, add_xy,
-                     add_marks, stride, before, after, mask);
+                     add_marks, stride, before, after, mask, Grid{grid_start, grid_items});
 }
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
-                                          double *e_pts, double *vectors) {
+                                          double *e_pts, double *vectors, const int32_t *grid_start,
+                                          const int32_t *grid_items) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_point_energies, dim3((n + 127) / 128), dim3(128), 0, st, P, tiles, tile, e_pts, vectors);
+  hipLaunchKernelGGL(k_point_energies, dim3((n + 127) / 128), dim3(128), 0, st, P, tiles, tile, e_pts, vectors,
+                     Grid{grid_start, grid_items});
 }
 extern "C" void mpp_launch_delta_batch(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                        int n_cases, const int32_t *rem_off, const int32_t *rem,
                                        const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
-                                       double *dE) {
+                                       double *dE, const int32_t *grid_start, const int32_t *grid_items) {
   if (n_cases <= 0) return;
   // one wave per perturbation: only the few points near the change do real work, so small workgroups keep more
   // perturbations in flight per CU than 256-thread ones (62 -> see DESIGN.md 6 ms for 5000 single-point removals)
   hipLaunchKernelGGL(k_delta_batch, dim3(n_cases), dim3(64), 0, st, P, tiles, tile, rem_off, rem, add_off, add_xy,
-                     add_marks, dE);
+                     add_marks, dE, Grid{grid_start, grid_items});
 }

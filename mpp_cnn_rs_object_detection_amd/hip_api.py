@@ -24,7 +24,7 @@ MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
-    "mpp_count", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
+    "mpp_count", "mpp_get_points_all", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
@@ -109,6 +109,7 @@ def load_library(path: Optional[str] = None):
         "mpp_set_points": (i32, [vp, i32, i32, vp, vp]),
         "mpp_get_points": (i32, [vp, i32, i32, C.POINTER(C.c_int32), vp, vp]),
         "mpp_count": (i32, [vp, i32, C.POINTER(C.c_int32)]),
+        "mpp_get_points_all": (i32, [vp, i32, vp, vp, vp]),
         "mpp_total_energy": (i32, [vp, i32, C.POINTER(dbl), vp]),
         "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
@@ -301,6 +302,21 @@ class MppContext:
         nn = C.c_int32()
         self._check(self._L.mpp_get_points(self._h, tile, n, C.byref(nn), _ptr(xy), _ptr(marks)))
         return xy, marks
+
+    def counts(self) -> np.ndarray:
+        """number of points of every tile (one device read)"""
+        n = np.zeros(self.get_option("n_chains"), np.int32)
+        self._check(self._L.mpp_get_points_all(self._h, 0, _ptr(n), None, None))
+        return n
+
+    def get_points_all(self):
+        """[(xy, marks)] of every tile with five strided device reads in total"""
+        n = self.counts()
+        cap = int(n.max()) if len(n) else 0
+        xy, marks = np.zeros((len(n), cap, 2), np.int32), np.zeros((len(n), cap, 3), np.float64)
+        if cap:
+            self._check(self._L.mpp_get_points_all(self._h, cap, _ptr(n), _ptr(xy), _ptr(marks)))
+        return [(xy[t, :n[t]], marks[t, :n[t]]) for t in range(len(n))]
 
     def naive_init(self, threshold: float, nms_distance: float = 6.0):
         self._check(self._L.mpp_naive_init(self._h, float(threshold), float(nms_distance)))

@@ -28,8 +28,8 @@ NMS_DISTANCE = 6.0      # reference sample_rjmcmc.py:27
 
 
 def _to_rectangles(xy: np.ndarray, marks: np.ndarray) -> List[Rectangle]:
-    return [Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2]))
-            for (x, y), m in zip(xy, marks)]
+    # (.tolist() first: building 5 000 rectangles from NumPy scalars took 54 ms of a 0.26 s scene, from Python numbers 8 ms)
+    return [Rectangle(x, y, size=s, ratio=r, angle=a) for (x, y), (s, r, a) in zip(xy.tolist(), marks.tolist())]
 
 
 def resolve_schedule(num_samples: int, init_temperature: float, alpha_t, burn_in, samples_interval,
@@ -104,7 +104,7 @@ class TileBatchSampler:
                 xy = np.array([[p.x, p.y] for p in cfg], dtype=np.int32).reshape(-1, 2)
                 mk = np.array([[p.size, p.ratio, p.angle] for p in cfg], dtype=np.float64).reshape(-1, 3)
                 self.ctx.set_points(i, xy, mk)
-        counts = np.array([self.ctx.count(i) for i in range(n)], dtype=np.float64)
+        counts = self.ctx.counts()[:n].astype(np.float64)
         self.intensity = np.maximum(1.0, counts)             # reference sample_rjmcmc.py:68
         self.ctx.set_kernels(make_kernels(self.mappings, 1.0, use_split_merge=self.use_split_merge), intensity=self.intensity)
 
@@ -120,14 +120,14 @@ class TileBatchSampler:
             self.ctx.run(t + 1 - done, seed, chain0)
             self.kernel_ms += self.ctx.last_kernel_ms()
             done = t + 1
-            for i in range(len(self.tiles)):
-                samples[i].append(_to_rectangles(*self.ctx.get_points(i)))
+            for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
+                samples[i].append(_to_rectangles(*pts))
         if done < total_steps:                                 # the reference keeps stepping to max_iter
             self.ctx.run(total_steps - done, seed, chain0)
             self.kernel_ms += self.ctx.last_kernel_ms()
         if not wanted:
-            for i in range(len(self.tiles)):
-                samples[i].append(_to_rectangles(*self.ctx.get_points(i)))
+            for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
+                samples[i].append(_to_rectangles(*pts))
         return samples
 
 

@@ -284,3 +284,37 @@ def test_soak_many_seeds_and_densities_against_the_oracle(setup_name):
         np.testing.assert_array_equal(gxy, oxy, err_msg=f"case {k}")
         np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9, err_msg=f"case {k}")
         assert ctx.total_energy() == pytest.approx(o.total_energy(), rel=1e-10, abs=1e-8)
+
+
+def test_get_points_all_equals_the_per_tile_reads():
+    """mpp_get_points_all (five strided copies for every tile) against mpp_get_points / mpp_count tile by tile, with
+    tiles of different populations, one of them empty, and a host capacity smaller than the largest tile."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    T, size = 5, 64
+    det = rng.random((T, size, size)).astype(np.float32)
+    marks = [rng.random((T, size, size, 32)).astype(np.float32) for _ in range(3)]
+    setup, comb, model = model_for("legacy")
+    ctx = hip_api.MppContext(0, point_capacity=128, spec_waves=1)
+    ctx.set_maps(det, marks); ctx.set_model(model, mappings.default_mappings())
+    pops = [7, 0, 31, 1, 12]
+    want = []
+    for t, n in enumerate(pops):
+        xy = rng.integers(0, size, size=(n, 2)).astype(np.int32)
+        mk = np.stack([rng.uniform(4, 12, n), rng.uniform(0.3, 0.9, n), rng.uniform(0, np.pi, n)], axis=1)
+        ctx.set_points(t, xy, mk)
+        want.append((xy, mk))
+    np.testing.assert_array_equal(ctx.counts(), pops)
+    for (xy, mk), (gxy, gmk), t in zip(want, ctx.get_points_all(), range(T)):
+        np.testing.assert_array_equal(gxy, xy); np.testing.assert_array_equal(gmk, mk)
+        pxy, pmk = ctx.get_points(t)
+        np.testing.assert_array_equal(gxy, pxy); np.testing.assert_array_equal(gmk, pmk)
+    cap = 10                                             # smaller than tile 2: the first `cap` points of it
+    n = np.zeros(T, np.int32); xy = np.full((T, cap, 2), -1, np.int32); mk = np.full((T, cap, 3), -1.0)
+    assert ctx._L.mpp_get_points_all(ctx._h, cap, n.ctypes.data_as(C.c_void_p), xy.ctypes.data_as(C.c_void_p),
+                                     mk.ctypes.data_as(C.c_void_p)) == 0
+    np.testing.assert_array_equal(n, pops)
+    for t in range(T):
+        k = min(pops[t], cap)
+        np.testing.assert_array_equal(xy[t, :k], want[t][0][:k]); np.testing.assert_array_equal(mk[t, :k], want[t][1][:k])
+        assert np.all(xy[t, k:] == -1)

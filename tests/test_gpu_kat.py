@@ -119,3 +119,56 @@ def test_spatial_hash_geometry_of_the_reference_test():
     pair64 = [E.PairTerm("far", E.P_DIST_LE, max_dist=64.0, reduce=E.REDUCE_MAX)]
     ctx.set_model(E.build_model_desc([E.UnitTerm("c", E.U_CONST, [1.0])], pair64, None), mappings.default_mappings())
     assert (ctx.get_option("grid_nx"), ctx.get_option("grid_ny"), ctx.get_option("grid_res")) == (4, 9, 64)
+
+
+@pytest.mark.parametrize("setup_name", ["legacy", "no-calibration"])
+def test_candidate_grid_of_the_from_scratch_energies(setup_name):
+    """Large configurations (a merged image) take their candidates from a uniform grid built on the device instead of
+    a scan of all points: energies, vectors, Papangelou values and multi-point deltas must be BIT-identical to the
+    full scan (max / min reductions do not depend on the visiting order), on a tile whose sides are not multiples of
+    the cell, with crowded cells, points on the border cells and perturbations that add and remove several points;
+    and both equal the oracle."""
+    from helpers import model_for
+    from mpp_cnn_rs_object_detection_amd import hip_api, mappings, synth
+    import oracle
+    H, W, n = 300, 421, 700
+    rng = np.random.default_rng(17)
+    gt_xy, gt_marks = synth.make_gt(max(H, W), 120, tile_id=3)
+    keep = (gt_xy[:, 0] < H) & (gt_xy[:, 1] < W)
+    det, marks = synth.render_maps((H, W), gt_xy[keep], gt_marks[keep], noise=0.2, noise_seed=2)
+    setup, comb, model = model_for(setup_name)
+    xy = np.stack([rng.integers(0, H, n), rng.integers(0, W, n)], axis=1).astype(np.int32)
+    xy[:40] = np.array([150, 200]) + rng.integers(-6, 7, size=(40, 2))          # a crowd in one cell
+    xy[40:44] = [[0, 0], [H - 1, W - 1], [0, W - 1], [H - 1, 0]]                # corners of the grid
+    mk = np.stack([rng.uniform(4, 12, n), rng.uniform(0.3, 0.9, n), rng.uniform(0, np.pi, n)], axis=1)
+    ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=1)
+    ctx.set_maps(det, marks); ctx.set_model(model, mappings.default_mappings()); ctx.set_points(0, xy, mk)
+    assert ctx.get_option("scratch_grid_min_points") == 256
+    removals = [[int(i)] for i in rng.integers(0, n, 30)] + [sorted(set(int(i) for i in rng.integers(0, n, 3))) for _ in range(20)] + [[]] * 10
+    add_xy, add_mk = [], []
+    for k in range(len(removals)):
+        m = int(rng.integers(0, 3)) if removals[k] else 2
+        base = xy[int(rng.integers(0, n))]
+        add_xy.append(np.clip(base + rng.integers(-10, 11, size=(m, 2)), 0, [H - 1, W - 1]).astype(np.int32))
+        add_mk.append(np.stack([rng.uniform(4, 12, m), rng.uniform(0.3, 0.9, m), rng.uniform(0, np.pi, m)], axis=1).reshape(m, 3))
+    nt = len(model.unit) + len(model.pair)
+    got = {}
+    for grid in (256, 0):
+        ctx.set_option("scratch_grid_min_points", grid)
+        e, vec = ctx.total_energy(0, return_vectors=True)
+        got[grid] = (e, vec, ctx.papangelou(0), ctx.delta_batch(0, removals, add_xy, add_mk),
+                     ctx.delta_vectors(0, removals, add_xy, add_mk, nt))
+    g, f = got[256], got[0]
+    assert g[0] == f[0]
+    np.testing.assert_array_equal(g[1], f[1]); np.testing.assert_array_equal(g[2], f[2]); np.testing.assert_array_equal(g[3], f[3])
+    for a, b in zip(g[4], f[4]):
+        np.testing.assert_array_equal(a, b)
+    o = oracle.Oracle((H, W), det, marks, model)
+    o.set_points(xy, mk)
+    e0, v0 = o.total_energy(return_vectors=True)
+    assert g[0] == pytest.approx(e0, rel=1e-9, abs=1e-7)
+    np.testing.assert_allclose(g[1], v0, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(g[2], o.papangelou(), rtol=1e-9, atol=1e-8)
+    for k in range(0, len(removals), 3):
+        d = o.delta(removal_slots=removals[k], add_xy=add_xy[k], add_marks=add_mk[k])
+        assert g[3][k] == pytest.approx(d, rel=1e-9, abs=1e-8), k
