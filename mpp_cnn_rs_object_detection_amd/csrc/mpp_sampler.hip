@@ -194,7 +194,116 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       __syncthreads();
     }
     PROF_ADD(9);
-    // ---- phase B: wave 0 commits in order
+    // ---- phase B, untraced wave mode: wave 0 DECIDES in order which records commit (registers, ballots and readlanes
+    //      only), then every chosen record is applied by the wave that evaluated it, all at once.  Two records of one
+    //      round that both commit neither share a slot, nor a cell, nor lie within 2*max_inter of each other, so they
+    //      touch disjoint cell lists, slots and cached reductions; a birth / death (which also changes n and order[])
+    //      is always the last record of its round.
+    const bool par_commit = !LANE && SPEC > 1 && !tracing;
+    if (par_commit) {
+      if (c.wave == 0) {
+        int committed = 0, cur_n = n;
+        double Tc = *(double *)(L.sh + 4);
+        const long long left = n_steps - done;
+        const int lim = left < (long long)SPEC ? (int)left : SPEC;
+        auto low = [](int k) -> unsigned long long { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); };
+        const unsigned long long lim_mask = low(lim);
+        const bool in = c.lane < lim;
+        const Rec &me = L.rec[in ? c.lane : 0];
+        bool ok = in && me.valid;
+        const int m_kern = me.kernel, m_hr = me.has_rem, m_ha = me.has_add, m_ts = me.tslot, m_nst = me.n_stash, m_pad = me._pad;
+        const int m_rx = me.rx, m_ry = me.ry, m_ax = me.ax, m_ay = me.ay;
+        int ci, cj;
+        const int m_cr = m_hr ? cell_index(P, m_rx, m_ry, &ci, &cj) : -1, m_ca = m_ha ? cell_index(P, m_ax, m_ay, &ci, &cj) : -2;
+        const unsigned long long acc_mask = __ballot(in && me.accepted && (m_hr || m_ha));
+        unsigned int commit_mask = 0;
+        int cur = 0;
+        while (true) {
+          const unsigned long long bad_mask = ~__ballot(ok) & lim_mask;
+          const int first_bad = bad_mask ? __ffsll((long long)bad_mask) - 1 : lim;
+          const unsigned long long todo = acc_mask & ~low(cur) & low(first_bad);
+          if (!todo) {
+            committed = first_bad;
+            if (first_bad < lim) {
+              const int kq = __builtin_amdgcn_readlane(m_kern, first_bad);
+              if (kq == -1) err = ERR_BAD_TARGET;
+              else if (kq <= -3) err = -2 - kq;
+              // otherwise: invalidated by an earlier accept of this round -> re-evaluated next round
+            }
+            break;
+          }
+          const int w = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+          if (__builtin_amdgcn_readlane(m_nst, w) > STASH && !apply_round) {     // redo this step alone in an apply round
+            if (c.lane == 0) L.sh[6] = 1;
+            committed = w;
+            break;
+          }
+          const int q_pad = __builtin_amdgcn_readlane(m_pad, w);
+          if (SM && q_pad != 0) { cur_n += q_pad; committed = w + 1; break; }    // a split / merge applied by sm_step()
+          const int q_hr = __builtin_amdgcn_readlane(m_hr, w), q_ha = __builtin_amdgcn_readlane(m_ha, w);
+          if (!(q_hr && q_ha)) {                                                 // death / birth: ends the round
+            if (q_hr) { commit_mask |= 1u << w; cur_n -= 1; }
+            else if (cur_n >= cap) err = ERR_POINT_OVERFLOW;
+            else { commit_mask |= 1u << w; cur_n += 1; }
+            committed = w + 1;
+            break;
+          }
+          commit_mask |= 1u << w;
+          // lane w2 > w: is record w2 still trustworthy after this move / transform?
+          const int q_ts = __builtin_amdgcn_readlane(m_ts, w), q_cr = __builtin_amdgcn_readlane(m_cr, w), q_ca = __builtin_amdgcn_readlane(m_ca, w);
+          const int qx[2] = {__builtin_amdgcn_readlane(m_rx, w), __builtin_amdgcn_readlane(m_ax, w)};
+          const int qy[2] = {__builtin_amdgcn_readlane(m_ry, w), __builtin_amdgcn_readlane(m_ay, w)};
+          if (c.lane > w && ok) {
+            bool bad = (m_hr && m_ts == q_ts) || m_cr == q_cr || m_cr == q_ca || m_ca == q_cr || m_ca == q_ca;
+            const int ox[2] = {m_rx, m_ax}, oy[2] = {m_ry, m_ay}, oh[2] = {m_hr, m_ha};
+            for (int a = 0; a < 2; ++a)
+              for (int b = 0; b < 2; ++b)
+                if (oh[a]) {
+                  int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
+                  if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
+                }
+            if (bad) ok = false;
+          }
+          cur = w + 1;
+        }
+        for (int i = 0; i < committed; ++i) if (Tc > T_target) Tc *= alpha;      // rjmcmc.py:158-159
+        if (c.lane == 0) {
+          L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; L.sh[3] = (int)commit_mask; *(double *)(L.sh + 4) = Tc;
+          if (apply_round) L.sh[6] = 0;
+        }
+      }
+      __syncthreads();
+      if ((((unsigned int)__builtin_amdgcn_readfirstlane(L.sh[3])) >> c.wave) & 1u) {     // my record commits: apply it
+        const Rec &q = r;
+        int e2 = 0;
+        if (!apply_round && c.lane < q.n_stash) {
+          int u = L.stash_slot[c.wave * STASH + c.lane];
+          L.red0[u] = L.stash_v0[c.wave * STASH + c.lane];
+          L.red1[u] = L.stash_v1[c.wave * STASH + c.lane];
+        }
+        wave_lds_fence();
+        int ci, cj;
+        if (q.has_rem && q.has_add) {                      // move / transform: same slot
+          int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
+          if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &e2); }
+          write_slot(c, q.tslot, q);
+        } else if (q.has_rem) {                            // death: last index takes the hole
+          cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
+          if (c.lane == 0) {
+            unsigned short last = L.order[n - 1];
+            L.order[n - 1] = (unsigned short)q.tslot;
+            L.order[q.tidx] = last;
+          }
+        } else {                                           // birth: next free slot
+          int slot = L.order[n];
+          cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &e2);
+          write_slot(c, slot, q);
+        }
+        if (e2 && c.lane == 0) L.sh[1] = e2;
+      }
+      PROF_ADD(2);
+    } else
+    // ---- phase B (traced tiles, lane mode, one wave): wave 0 commits in order
     if (c.wave == 0) {
       int committed = 0, cur_n = n;
       double Tc = *(double *)(L.sh + 4);
