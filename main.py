@@ -25,7 +25,8 @@ def main():
     parser.add_argument("-o", "--overwrite", action="store_true", help="overwrite existing results")
     parser.add_argument("-r", "--resume", action="store_true", help="(training) resume from checkpoint")
     parser.add_argument("--spec-waves", type=int, default=None,
-                        help="speculative waves per chain (1,2,4,8,16); default: 8 for fewer than 768 tiles per launch, else 1")
+                        help="speculative waves per chain (1,2,4,8,16); default: chosen per launch from the number of tiles and the "
+                             "LDS footprint of a chain (sampler.choose_spec_waves)")
     parser.add_argument("--unet", action="store_true", help="compute the score maps with the U-Nets on the GPU "
                                                             "instead of reading NNNN_results.pkl")
     args = parser.parse_args()

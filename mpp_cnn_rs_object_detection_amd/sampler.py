@@ -55,6 +55,28 @@ def resolve_schedule(num_samples: int, init_temperature: float, alpha_t, burn_in
     return float(alpha_t), float(target_temperature), total, snaps
 
 
+#: relative speed of ONE chain with 8 / 4 / 2 / 1 speculative waves (profiles/r01_batched_sweep.json, saturated launches:
+#: 322 k / 238 k / 150 k / 96 k proposals/s per chain on 256-px tiles)
+SPEC_SPEED = {8: 1.0, 4: 0.74, 2: 0.47, 1: 0.30}
+LDS_PER_CU, WAVES_PER_CU, N_CU = 160 * 1024, 8, 256      # MI355X; 8 waves of 256 VGPRs fill a CU
+
+
+def choose_spec_waves(ctx: MppContext, n_tiles: int, use_split_merge: bool = False) -> int:
+    """Speculative waves per chain for a launch of ``n_tiles`` chains: fewer waves per chain let more chains share a
+    CU -- if their LDS footprint (set by the point capacity) allows it.  Minimises rounds-of-workgroups / chain speed.
+    With the default capacity of 1024 slots one chain fills a CU's LDS and 8 waves are always best; with 128 slots the
+    measured optimum is 8 waves up to 256 tiles, 4 up to 512, 2 up to 1024, 1 beyond (same sweep)."""
+    best, best_t = 8, None
+    for spec in ((8, 1) if use_split_merge else (8, 4, 2, 1)):
+        ctx.set_option("spec_waves", spec)
+        lds = max(1, ctx.get_option("lds_bytes"))
+        resident = N_CU * max(1, min(LDS_PER_CU // lds, WAVES_PER_CU // spec))
+        t = -(-n_tiles // resident) / SPEC_SPEED[spec]
+        if best_t is None or t < best_t - 1e-12:
+            best, best_t = spec, t
+    return best
+
+
 class TileBatchSampler:
     """All tiles of an image (or of a batch of images) sampled concurrently on one GPU."""
 
@@ -71,11 +93,8 @@ class TileBatchSampler:
         self.mappings = tiles[0].mappings
         unit, pair = energy_setup.make_energies(tiles[0])
         self.model = E.build_model_desc(unit, pair, energy_combinator)
-        if spec_waves is None:
-            # few chains: 8 speculative waves per chain shorten each of them; many chains: one wave per chain fills the
-            # GPU better (profiles/r01_batched_sweep.json: 256 chains 80 vs 29 M proposals/s, crossover near 700)
-            spec_waves = 8 if len(tiles) < 768 else 1
-        self.ctx = ctx or MppContext(device, point_capacity=point_capacity, spec_waves=spec_waves)
+        auto_spec = spec_waves is None
+        self.ctx = ctx or MppContext(device, point_capacity=point_capacity, spec_waves=8 if auto_spec else spec_waves)
         det0 = tiles[0].detection_map
         if hasattr(det0, "data_ptr"):                 # maps already on the GPU (U-Net epilogue output)
             import torch
@@ -86,6 +105,8 @@ class TileBatchSampler:
             marks = [np.stack([np.asarray(t.param_dist_maps[k], dtype=np.float32) for t in tiles]) for k in range(3)]
         self.ctx.set_maps(det, marks)
         self.ctx.set_model(self.model, self.mappings)
+        if auto_spec and ctx is None:
+            self.ctx.set_option("spec_waves", choose_spec_waves(self.ctx, len(self.tiles), use_split_merge))
 
     def init(self, init_config: Union[str, None, Sequence[Sequence[Rectangle]]]):
         n = len(self.tiles)

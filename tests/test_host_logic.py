@@ -164,3 +164,30 @@ def test_labels_to_rectangles_on_the_reference_data_sample():
     assert got.shape == (272, 5)
     np.testing.assert_allclose(got, z["ref_rects"], rtol=1e-13, atol=1e-13)
     assert (got[:, 3] > 0).all() and (got[:, 3] <= 1).all() and (got[:, 4] >= 0).all() and (got[:, 4] < np.pi).all()
+
+
+def test_choose_spec_waves_follows_the_measured_optimum():
+    """The launch policy (speculative waves per chain from the number of tiles and a chain's LDS footprint) against the
+    sweep in profiles/r01_batched_sweep.json: with 1024 slots one chain fills a CU's LDS -> always 8 waves; with 128 slots
+    8 waves up to 256 tiles, 4 up to 512, 2 up to 1024, 1 beyond.  Split / merge kernels exist for 1 and 8 waves only."""
+    from mpp_cnn_rs_object_detection_amd.sampler import choose_spec_waves
+
+    class FakeCtx:
+        def __init__(self, lds_of):
+            self.lds_of, self.spec = lds_of, 8
+
+        def set_option(self, name, v):
+            assert name == "spec_waves"
+            self.spec = v
+
+        def get_option(self, name):
+            assert name == "lds_bytes"
+            return self.lds_of(self.spec)
+
+    big = FakeCtx(lambda spec: 100 * 1024 + 1024 * spec)          # point_capacity 1024
+    small = FakeCtx(lambda spec: 16 * 1024 + 1024 * spec)         # point_capacity 128
+    for tiles in (1, 64, 256, 512, 1024, 4096):
+        assert choose_spec_waves(big, tiles) == 8
+    assert [choose_spec_waves(small, t) for t in (1, 256, 257, 512, 513, 1024, 1025, 2048, 4096, 16384)] == \
+        [8, 8, 4, 4, 2, 2, 1, 1, 1, 1]
+    assert [choose_spec_waves(small, t, use_split_merge=True) for t in (256, 512, 2048)] == [8, 8, 1]
