@@ -58,8 +58,8 @@ def main():
     ap.add_argument("--cpu-baseline-chains", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence", action="store_true", help="skip the (untimed) wall-clock-to-convergence chain")
-    ap.add_argument("--batched-tiles", type=int, default=0,
-                    help="extra, untimed-in-`value` measurement: this many 256x256 tiles (the reference's tile size, "
+    ap.add_argument("--batched-tiles", type=int, default=4096,
+                    help="extra measurement, never part of `value` (0 = skip): this many 256x256 tiles (the reference's tile size, "
                          "50 objects, mpp_hrcM schedule of 30257 steps) sampled concurrently, one workgroup per tile")
     ap.add_argument("--batched-spec", type=int, default=1)
     ap.add_argument("--batched-tile", type=int, default=256)
@@ -222,7 +222,7 @@ def main():
         bctx.set_maps(np.stack([t.det for t in base]), [np.stack([t.marks[k] for t in base]) for k in range(3)])
         bctx.set_model(model, maps)
         bctx.naive_init(setup.detection_threshold, 6.0)
-        binten = np.array([max(1, bctx.count(i)) for i in range(B)], dtype=np.float64)
+        binten = np.maximum(1, bctx.counts()[:B]).astype(np.float64)
         bctx.set_kernels(kernels.make_kernels(maps, 1.0), intensity=binten)
         bctx.set_schedule(T0, alpha, Tt)
         bctx.run(2000, seed=1)                                        # warm-up
@@ -232,7 +232,7 @@ def main():
         bctx.run(biters, seed=2)
         wall = time.perf_counter() - tb
         kms = bctx.last_kernel_ms()
-        n_end = np.array([bctx.count(i) for i in range(B)])
+        n_end = bctx.counts()[:B]
         brate = B * biters / (kms * 1e-3)
         bbpp = bytes_per_proposal(float(n_end.mean()), (bt // 32) ** 2, acc)
         result["batched"] = {
