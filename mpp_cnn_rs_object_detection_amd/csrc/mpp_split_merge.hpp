@@ -153,7 +153,13 @@ __device__ inline void sm_draw(const Chain &c, Rec &r, int ri, int n, const uint
   }
   const int cnt = sm_neighbours(c, ri, r.tslot, r.rx, r.ry);
   if (cnt > STASH) { *err = ERR_CAND_OVERFLOW; r.has_rem = 0; return; }
-  if (cnt == 0) { r.has_rem = 0; return; }            // p0 has no neighbour: empty perturbation (:124-126)
+  if (cnt == 0) {                                     // p0 has no neighbour: empty perturbation (:124-126)
+    // ... if the search ran on the state this step will really see: record 0 of a round always does.  A later record of
+    // the round may have searched around a point that an earlier step of the round moves: it stays a merge with a
+    // target, i.e. it asks for an apply round, where it is record 0 and is drawn again on the live state.
+    if (ri == 0) r.has_rem = 0;
+    return;
+  }
   const int slot1 = sm_pick(c, ri, cnt, (int)mulhi32(w[3], (uint32_t)cnt));
   r.pid = sm_dense_index(c, n, slot1);
 }

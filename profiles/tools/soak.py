@@ -1,0 +1,47 @@
+"""Soak of the production chain kernel (8 speculative waves, untraced) against the C oracle: random tile sizes,
+densities, crowding, temperatures, both energy setups, with and without split / merge kernels (tests/helpers.py:
+soak_case); the final configurations must agree (centres exactly, marks to 1e-9).
+`python profiles/tools/soak.py [cases] [first]` on the GPU box; one line per case and a summary.  A verification run, not
+part of the test suite (~0.6 s per case); the cases it ever caught are regression tests in tests/test_gpu_chain.py."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import oracle  # noqa: E402
+from helpers import soak_case  # noqa: E402
+from mpp_cnn_rs_object_detection_amd import hip_api, mappings  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad, skipped = [], 0
+t0 = time.time()
+for k in range(first, first + n_cases):
+    c = soak_case(k)
+    t = c["tile"]
+    o = oracle.Oracle(t.shape, t.det, t.marks, c["model"], c["kd"])
+    o.set_points(c["xy"], c["marks"]); o.set_temperature(c["T0"], c["alpha"], 0.0)
+    o.run(c["steps"], c["seed"], chain=c["chain"])
+    oxy, om = o.get_points()
+    ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=8)
+    ctx.set_maps(t.det, t.marks); ctx.set_model(c["model"], mappings.default_mappings()); ctx.set_kernels(c["kd"])
+    ctx.set_points(0, c["xy"], c["marks"]); ctx.set_schedule(c["T0"], c["alpha"], 0.0)
+    try:
+        ctx.run(c["steps"], c["seed"], chain0=c["chain"])
+    except hip_api.MppError as e:        # a hot chain may crowd more than 32 points into one 32-px cell: reported, not hidden
+        skipped += 1
+        print(f"case {k}: {c['text']} stopped ({e})", flush=True)
+        ctx.close()
+        continue
+    gxy, gm = ctx.get_points()
+    ctx.close()
+    ok = gxy.shape == oxy.shape and np.array_equal(gxy, oxy) and np.allclose(gm, om, rtol=1e-9, atol=1e-9)
+    if not ok:
+        bad.append(k)
+    print(f"case {k}: {c['text']} n_end={len(oxy)} {'ok' if ok else 'MISMATCH'}", flush=True)
+print(f"{n_cases - len(bad) - skipped} of {n_cases} cases agree with the oracle, {skipped} stopped with a capacity error, "
+      f"mismatches: {bad}; {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)

@@ -132,3 +132,31 @@ class Tape:
 def sorted_rows(a):
     a = np.asarray(a, dtype=float).reshape(-1, 5)
     return a[np.lexsort(a.T[::-1])] if len(a) else a
+
+
+def soak_case(k: int):
+    """Case k of the chain soak (profiles/tools/soak.py and the regression tests): a random tile, density, crowding,
+    temperature, energy setup and kernel mixture, each case from its own generator so that it can be replayed alone.
+    -> dict(tile, setup, model, kd (kernels), xy, marks, T0, alpha, steps, seed, chain, text)"""
+    import oracle
+    rng = np.random.default_rng([2026, k])
+    size = int(rng.choice([64, 96, 128, 160, 200, 256]))
+    n_obj = int(rng.integers(5, max(6, (size // 14) ** 2 // 2)))
+    setup_name = str(rng.choice(["legacy", "no-calibration"]))
+    sm = bool(rng.random() < 0.3)
+    T0, alpha = float(rng.choice([0.3, 1.0, 2.0, 5.0])), float(rng.choice([0.999, 0.9995, 0.9999]))
+    steps, seed, chain = int(rng.integers(3000, 20000)), int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 1000))
+    crowd = bool(rng.random() < 0.3)
+    t = synth.make_tile(size, n_obj, tile_id=5000 + k, noise=float(rng.choice([0.0, 0.1, 0.3])))
+    setup, comb, model = model_for(setup_name)
+    maps = mappings.default_mappings()
+    o = oracle.Oracle(t.shape, t.det, t.marks, model, kernels.make_kernels(maps, 1.0))
+    xy, mk = o.naive_detection(setup.detection_threshold, 6.0)
+    if crowd and len(xy):
+        xy = np.concatenate([xy, np.clip(xy + rng.integers(-4, 5, size=xy.shape), 0, size - 1)]).astype(np.int32)
+        mk = np.concatenate([mk, mk])
+    kd = kernels.make_kernels(maps, float(max(1, len(xy))), use_split_merge=sm)
+    text = (f"{size}px {setup_name} split/merge={int(sm)} crowd={int(crowd)} T0={T0} alpha={alpha} steps={steps} "
+            f"seed={seed} chain={chain} n0={len(xy)}")
+    return dict(tile=t, setup=setup, model=model, kd=kd, xy=xy, marks=mk, T0=T0, alpha=alpha, steps=steps, seed=seed,
+                chain=chain, text=text)
