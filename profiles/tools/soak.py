@@ -1,7 +1,7 @@
 """Soak of the production chain kernel (8 speculative waves, untraced) against the C oracle: random tile sizes,
 densities, crowding, temperatures, both energy setups, with and without split / merge kernels (tests/helpers.py:
 soak_case); the final configurations must agree (centres exactly, marks to 1e-9).
-`python profiles/tools/soak.py [cases] [first]` on the GPU box; one line per case and a summary.  A verification run, not
+`python profiles/tools/soak.py [cases] [first] [sm]` on the GPU box; one line per case and a summary.  A verification run, not
 part of the test suite (~0.6 s per case); the cases it ever caught are regression tests in tests/test_gpu_chain.py."""
 import os
 import sys
@@ -17,10 +17,14 @@ from mpp_cnn_rs_object_detection_amd import hip_api, mappings  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only_sm = len(sys.argv) > 3 and sys.argv[3] == "sm"      # only the cases with split / merge kernels
 bad, skipped = [], 0
 t0 = time.time()
 for k in range(first, first + n_cases):
     c = soak_case(k)
+    if only_sm and "split/merge=1" not in c["text"]:
+        skipped += 1
+        continue
     t = c["tile"]
     o = oracle.Oracle(t.shape, t.det, t.marks, c["model"], c["kd"])
     o.set_points(c["xy"], c["marks"]); o.set_temperature(c["T0"], c["alpha"], 0.0)
@@ -42,6 +46,6 @@ for k in range(first, first + n_cases):
     if not ok:
         bad.append(k)
     print(f"case {k}: {c['text']} n_end={len(oxy)} {'ok' if ok else 'MISMATCH'}", flush=True)
-print(f"{n_cases - len(bad) - skipped} of {n_cases} cases agree with the oracle, {skipped} stopped with a capacity error, "
+print(f"{n_cases - len(bad) - skipped} of {n_cases} cases agree with the oracle, {skipped} stopped with a capacity error or filtered out, "
       f"mismatches: {bad}; {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
