@@ -147,6 +147,14 @@ int mpp_count(mpp_ctx *ctx, int tile, int32_t *n);
 /* all tiles at once (the per-tile results `Pool.map` hands back, mpp_model.py:250-262): n[n_tiles]; if xy and marks are
  * not NULL, xy [n_tiles][cap][2] and marks [n_tiles][cap][3] receive the first min(n[t], cap) points of every tile */
 int mpp_get_points_all(mpp_ctx *ctx, int cap, int32_t *n, int32_t *xy, double *marks);
+/* The configurations of tiles 0..n-1 of the ctx packed into ONE fixed-capacity record buffer ON THE DEVICE: the send
+ * buffer of the all-gather (RCCL over xGMI) that stands in for the result list `Pool.map` returns in
+ * mpp_model.py:250-262.  out_dev [capacity+1][7] float64 (device pointer of this ctx's GPU): row 0 = (count, 0...),
+ * row 1+k = (tile_ids[t], x + anchors[t][0], y + anchors[t][1], size, ratio, angle, 0) -- image coordinates as
+ * merge_patches forms them (data_loaders.py:133-138), tiles in order, points in slot order; the rest is zeroed.
+ * tile_ids [n], anchors [n][2]: host arrays.  count (may be NULL) receives the number of records; -4 if > capacity. */
+int mpp_pack_detections(mpp_ctx *ctx, int n, const int32_t *tile_ids, const int32_t *anchors, int capacity,
+                        double *out_dev, int32_t *count);
 /* total_energy(): combined energy and, optionally, [n][n_unit+n_pair] per-point vectors */
 int mpp_total_energy(mpp_ctx *ctx, int tile, double *energy, double *vectors_or_null);
 /* energy_delta(Perturbation) for a batch of perturbations with list removals/additions:

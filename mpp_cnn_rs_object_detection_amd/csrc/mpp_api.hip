@@ -30,6 +30,8 @@ extern "C" int mpp_launch_shapenet_epilogue_nhwc(hipStream_t st, const void *log
 extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad,
                                     int pool, int in_bytes, int out_bytes, const float *scale, const float *shift);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
+extern "C" void mpp_launch_pack_detections(hipStream_t st, const TileRef *tiles, int n_tiles, const int32_t *tile_ids,
+                                           const int32_t *anchors, int capacity, double *out);
 extern "C" void mpp_launch_point_energies(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile, int n,
                                           double *e_pts, double *vectors, const int32_t *grid_start,
                                           const int32_t *grid_items);
@@ -129,7 +131,8 @@ static const char *chain_error_text(int e) {
   return "unknown chain error";
 }
 
-extern "C" int mpp_abi_version(void) { return 3; }   // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc
+// 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections
+extern "C" int mpp_abi_version(void) { return 4; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -516,6 +519,32 @@ extern "C" int mpp_get_points_all(mpp_ctx *c, int cap, int32_t *n_out, int32_t *
       marks[3 * dst] = s[src]; marks[3 * dst + 1] = r[src]; marks[3 * dst + 2] = a[src];
     }
   }
+  return 0;
+}
+
+extern "C" int mpp_pack_detections(mpp_ctx *c, int n, const int32_t *tile_ids, const int32_t *anchors, int capacity,
+                                   double *out_dev, int32_t *count) {
+  if (!c || !c->have_maps || n <= 0 || n > c->n_tiles || !tile_ids || !anchors || capacity < 0 || !out_dev)
+    return fail(c, -1, "bad pack_detections arguments");
+  int rc = push_state(c);
+  if (rc) return rc;
+  int32_t *d_meta = nullptr;
+  HIPCHK(c, dalloc(&d_meta, (size_t)3 * n));
+  hipError_t e = hipMemcpyAsync(d_meta, tile_ids, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_meta + n, anchors, (size_t)2 * n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(out_dev, 0, ((size_t)capacity + 1) * 7 * sizeof(double), c->stream);
+  double total = 0.0;
+  if (e == hipSuccess) {
+    mpp_launch_pack_detections(c->stream, c->d_tiles, n, d_meta, d_meta + n, capacity, out_dev);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&total, out_dev, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  hipError_t e2 = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_meta);
+  HIPCHK(c, e); HIPCHK(c, e2);
+  if (count) *count = (int32_t)total;
+  if ((int)total > capacity)
+    return fail(c, -4, "%d detections exceed the gather buffer's capacity %d", (int)total, capacity);
   return 0;
 }
 

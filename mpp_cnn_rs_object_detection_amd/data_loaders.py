@@ -51,16 +51,17 @@ def labels_to_rectangles(labels: Dict, param_names: Sequence[str] = PARAM_NAMES)
 
 
 def load_image_w_maps(patch_id, dataset: str, subset: str, position_model: str, shape_model: str,
-                      nets=None) -> ImageWMaps:
+                      nets=None, defer_maps: bool = False) -> ImageWMaps:
     """Reference ``data_loaders.py:30-71``.  With ``nets`` (a ``ScoreMapNets``) the maps are computed on the GPU
-    instead of being read from the inference pickles."""
+    instead of being read from the inference pickles; ``defer_maps``: leave them ``None`` (the caller runs the nets on
+    the part of the image its rank owns, ``MPPModel.region_maps``)."""
     from matplotlib import pyplot as plt
     patch_id = int(patch_id)
     base = os.path.join(get_dataset_base_path(), dataset, subset)
     image = plt.imread(os.path.join(base, "images", f"{patch_id:04}.png"))[:, :, :3]
     labels = _load_pickle(os.path.join(base, "annotations", f"{patch_id:04}.pkl"))
     if nets is not None:
-        det, marks = nets.infer(image)
+        det, marks = (None, None) if defer_maps else nets.infer(image)
         maps = _mappings.default_mappings()
     else:
         pos = _load_pickle(os.path.join(get_inference_path(position_model, dataset, subset), f"{patch_id:04}_results.pkl"))
@@ -105,11 +106,36 @@ def crop_image_w_maps(image_data: ImageWMaps, tl_anchor: np.ndarray, patch_size:
                       crop_data={"tl_anchor": np.array([x, y])})
 
 
+def distance_merge(xy: np.ndarray, scores: np.ndarray, distance: float) -> np.ndarray:
+    """The dedupe rule of the reference's ``merge_patches(method='distance')`` (``data_loaders.py:140-159``) as a
+    function of the aggregated points alone: walking the points in order, every not-yet-removed point keeps, among
+    the not-yet-removed points within ``distance`` of it (itself included), only the one with the best Papangelou
+    intensity.  Returns the mask of removed points.  Deterministic in its inputs, so ranks that hold the same
+    gathered points and scores take the same decision."""
+    n = len(xy)
+    removed = np.zeros(n, dtype=bool)
+    if n == 0:
+        return removed
+    from scipy.spatial import cKDTree                  # neighbour lists once (integer coordinates: exact comparisons)
+    xy = np.asarray(xy, dtype=float).reshape(-1, 2)
+    balls = cKDTree(xy).query_ball_point(xy, r=float(distance))
+    for i in range(n):
+        if removed[i]:
+            continue
+        near = np.array(sorted(j for j in balls[i] if not removed[j]), dtype=np.int64)
+        if len(near) == 0:
+            continue
+        best = near[np.argmax(scores[near])]
+        removed[near] = True
+        removed[best] = False
+    return removed
+
+
 def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], original_image: ImageWMaps, energy_model,
-                  method: str, energy_setup, **kwargs):
+                  method: str, energy_setup, device: int = 0, **kwargs):
     """Reference ``data_loaders.py:122-161``: shift every tile's detections by its anchor, then (method
     'distance') keep, among points closer than ``distance``, the one with the best Papangelou intensity
-    in the FULL aggregated configuration.  The intensities of all points come from one GPU launch."""
+    in the FULL aggregated configuration.  The intensities of all points come from one GPU launch on ``device``."""
     assert method in ["distance", "rjmcmc"]
     unit, pair = energy_setup.make_energies(original_image)
     merged: List[Rectangle] = []
@@ -119,28 +145,27 @@ def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], ori
             q = copy(r)
             q.x, q.y = int(q.x + ax), int(q.y + ay)
             merged.append(q)
-    agg = EPointsSet(merged, original_image.shape, unit, pair, image_data=original_image,
+    agg = EPointsSet(merged, original_image.shape, unit, pair, image_data=original_image, device=device,
                      point_capacity=max(1024, len(merged) + 64))
     if method == "distance" and len(merged) > 0:
-        distance = kwargs["distance"]
         scores = agg.papangelou_all(energy_combinator=energy_model)
-        xy = np.array([[p.x, p.y] for p in merged], dtype=float)
-        removed = np.zeros(len(merged), dtype=bool)
-        from scipy.spatial import cKDTree              # neighbour lists once (integer coordinates: exact comparisons)
-        balls = cKDTree(xy).query_ball_point(xy, r=float(distance))
-        for i in range(len(merged)):
-            if removed[i]:
-                continue
-            near = np.array(sorted(j for j in balls[i] if not removed[j]), dtype=np.int64)
-            if len(near) == 0:
-                continue
-            best = near[np.argmax(scores[near])]
-            removed[near] = True
-            removed[best] = False
+        removed = distance_merge(np.array([[p.x, p.y] for p in merged], dtype=float), scores, kwargs["distance"])
         logging.info(f"merge removing {int(removed.sum())} point(s)")
         for i in np.nonzero(removed)[0]:
             agg.remove(merged[i])
     return agg
+
+
+def crop_region(image_data: ImageWMaps, region) -> ImageWMaps:
+    """The score maps of the image region ``(x0, x1, y0, y1)`` as an ``ImageWMaps`` of its own (views, no copy);
+    ``crop_data['tl_anchor']`` holds the region's origin in image coordinates."""
+    x0, x1, y0, y1 = (int(v) for v in region)
+    sl = (slice(x0, x1), slice(y0, y1))
+    det = image_data.detection_map[sl]
+    return ImageWMaps(image=image_data.image[sl] if image_data.image is not None else None, name=image_data.name,
+                      shape=(x1 - x0, y1 - y0), detection_map=det, param_dist_maps=[m[sl] for m in image_data.param_dist_maps],
+                      mappings=image_data.mappings, param_names=PARAM_NAMES, labels=None, gt_config=[],
+                      crop_data={"tl_anchor": np.array([x0, y0]), "full_shape": tuple(image_data.shape[:2])})
 
 
 class MPPDataset:

@@ -24,7 +24,7 @@ MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
-    "mpp_count", "mpp_get_points_all", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
+    "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
@@ -110,6 +110,7 @@ def load_library(path: Optional[str] = None):
         "mpp_get_points": (i32, [vp, i32, i32, C.POINTER(C.c_int32), vp, vp]),
         "mpp_count": (i32, [vp, i32, C.POINTER(C.c_int32)]),
         "mpp_get_points_all": (i32, [vp, i32, vp, vp, vp]),
+        "mpp_pack_detections": (i32, [vp, i32, vp, vp, i32, vp, C.POINTER(C.c_int32)]),
         "mpp_total_energy": (i32, [vp, i32, C.POINTER(dbl), vp]),
         "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
@@ -197,6 +198,7 @@ class MppContext:
         if rc != 0:
             raise MppError(rc, "mpp_create failed: no usable MI355X/HIP device" if rc == -3 else "mpp_create failed")
         self._h = h
+        self.device = int(device)
         self._keep = []          # keeps borrowed device tensors / host arrays alive
         self.n_tiles = 0
         self.shape = (0, 0)
@@ -254,6 +256,9 @@ class MppContext:
             arrs = [a.contiguous() if a.dtype == torch.float32 else a.float().contiguous() for a in [det] + list(marks)]
             if not all(a.is_cuda for a in arrs):
                 raise TypeError("torch maps must live on the GPU")
+            if any(a.device.index != self.device for a in arrs):
+                # borrowed pointers are dereferenced by kernels launched on this ctx's GPU; peer access is never enabled
+                raise ValueError(f"borrowed maps live on {arrs[0].device} but this context is bound to GPU {self.device}")
             shape = tuple(arrs[0].shape)
         else:
             arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in [det] + list(marks)]
@@ -317,6 +322,22 @@ class MppContext:
         if cap:
             self._check(self._L.mpp_get_points_all(self._h, cap, _ptr(n), _ptr(xy), _ptr(marks)))
         return [(xy[t, :n[t]], marks[t, :n[t]]) for t in range(len(n))]
+
+    def pack_detections(self, tile_ids, anchors, capacity: int, out) -> int:
+        """Every tile's configuration as records (tile id, x + anchor_x, y + anchor_y, size, ratio, angle, 0) in the
+        device tensor ``out`` [capacity+1, 7] float64 (row 0 = count): the all-gather's send buffer, filled without a
+        host round trip.  Returns the number of records."""
+        tile_ids = np.ascontiguousarray(tile_ids, dtype=np.int32).reshape(-1)
+        anchors = np.ascontiguousarray(anchors, dtype=np.int32).reshape(-1, 2)
+        if len(tile_ids) != len(anchors) or len(tile_ids) > self.n_tiles:
+            raise ValueError("pack_detections: one id and one anchor per tile of the context")
+        if not (_is_torch(out) and out.is_cuda and out.device.index == self.device and out.is_contiguous()
+                and tuple(out.shape) == (capacity + 1, 7) and out.element_size() == 8):
+            raise ValueError(f"pack_detections: out must be a contiguous [{capacity + 1}, 7] float64 tensor on GPU {self.device}")
+        n = C.c_int32()
+        self._check(self._L.mpp_pack_detections(self._h, len(tile_ids), _ptr(tile_ids), _ptr(anchors), int(capacity),
+                                                _ptr(out), C.byref(n)))
+        return n.value
 
     def naive_init(self, threshold: float, nms_distance: float = 6.0):
         self._check(self._L.mpp_naive_init(self._h, float(threshold), float(nms_distance)))

@@ -25,7 +25,9 @@ import numpy as np
 from . import distributed as mdist
 from . import energies as E
 from .custom_types import ImageWMaps
-from .data_loaders import PATCH_SIZE, crop_image_w_maps, load_image_w_maps, merge_patches, tile_anchors
+from .data_loaders import (PATCH_SIZE, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps, merge_patches,
+                           tile_anchors)
+from .point_set import EPointsSet
 from .dota_results import DOTAResultsTranslator
 from .paths import fetch_data_paths, get_inference_path, get_model_base_path
 from .sampler import TileBatchSampler, resolve_schedule
@@ -206,47 +208,150 @@ class MPPModel:
             json.dump(d, f, indent=1)
 
     # ------------------------------------------------------------------------------------------------
-    def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1):
-        """Tile, sample, merge and score one image.  Returns (EPointsSet of detections, scores)."""
-        shape = image_data.shape[:2]
+    #: a rank needs score maps on its tiles plus this margin: every point a detection of one of its tiles interacts
+    #: with (pair energies reach 32 px, prior_energies.py / energy_graph.py:26-29) then has its unit energies available
+    SCORE_MARGIN = 32
+
+    def tile_layout(self, shape):
+        """(patch size, anchors) of an image: the reference's overlapping 256-px tiles (``mpp_model.py:231-248``)"""
         patch = min(PATCH_SIZE, shape[0], shape[1])
-        anchors = tile_anchors(shape, patch)
-        tiles = [crop_image_w_maps(image_data, a, patch) for a in anchors]
-        mine = mdist.shard_tiles(len(tiles), rank, world_size)
+        return patch, tile_anchors(shape, patch)
+
+    def own_region(self, shape, rank: int, world_size: int):
+        """The image region ``(x0, x1, y0, y1)`` rank needs score maps for: the bounding box of its block of tiles
+        plus ``SCORE_MARGIN``, clipped to the image; ``None`` for a rank without tiles; the whole image for one rank."""
+        if world_size == 1:
+            return (0, int(shape[0]), 0, int(shape[1]))
+        patch, anchors = self.tile_layout(shape)
+        mine = mdist.shard_tiles(len(anchors), rank, world_size)
+        if not mine:
+            return None
+        xs, ys, m = [anchors[i][0] for i in mine], [anchors[i][1] for i in mine], self.SCORE_MARGIN
+        return (max(0, int(min(xs)) - m), min(int(shape[0]), int(max(xs)) + patch + m),
+                max(0, int(min(ys)) - m), min(int(shape[1]), int(max(ys)) + patch + m))
+
+    def region_maps(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1) -> Optional[ImageWMaps]:
+        """Score maps of this rank's region as an ``ImageWMaps`` in region coordinates: a view of the image's maps when
+        it has them (pickle hand-off), otherwise the two U-Nets run on the region plus their halo
+        (``ScoreMapNets.infer_region``) -- each rank's forward covers its own tiles only."""
+        region = self.own_region(image_data.shape[:2], rank, world_size)
+        if region is None:
+            return None
+        if image_data.detection_map is not None:
+            return crop_region(image_data, region)
+        if self.nets is None:
+            raise ValueError("the image carries no score maps and no nets were given")
+        det, marks = self.nets.infer_region(image_data.image, region)
+        x0, x1, y0, y1 = region
+        return ImageWMaps(image=None, name=image_data.name, shape=(x1 - x0, y1 - y0), detection_map=det,
+                          param_dist_maps=marks, mappings=image_data.mappings, param_names=image_data.param_names,
+                          gt_config=[], crop_data={"tl_anchor": np.array([x0, y0]), "full_shape": tuple(image_data.shape[:2])})
+
+    def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1, region_data: ImageWMaps = None):
+        """Tile, sample, merge and score one image.  Returns (detections, scores): an ``EPointsSet`` for one rank,
+        the list of merged ``Rectangle``s on every rank of a multi-GPU run (all ranks return the same).
+
+        Multi-GPU (reference: the process pool of ``mpp_model.py:250-262``): rank r samples its block of tiles on the
+        score maps of its own region, the sampled configurations are packed on the device and all-gathered once,
+        every rank scores the gathered points of ITS tiles on its own maps (their neighbours lie inside the region by
+        construction), one all-reduce shares the scores, every rank takes the same ``distance_merge`` decision, and a
+        second scoring + all-reduce gives the final Papangelou scores of the survivors."""
+        shape = tuple(int(v) for v in image_data.shape[:2])
+        patch, anchors = self.tile_layout(shape)
+        n_tiles = len(anchors)
+        mine = mdist.shard_tiles(n_tiles, rank, world_size)
         p = self.config["inference"]["rjmcmc_params"]
         alpha, T_target, total, snaps = resolve_schedule(1, p["init_temperature"], p["alpha_t"], p["burn_in"],
                                                           p["samples_interval"], p["target_temperature"],
                                                           p.get("iter_multiplier"))
-        results: List[List[Rectangle]] = [[] for _ in tiles]
+        # drawn by every rank for every image, with or without tiles of its own: the generators of all ranks stay in
+        # step, so the result does not depend on the number of ranks
+        seed = int(self.rng.integers(0, 2 ** 63 - 1))
+        if region_data is None:
+            region_data = self.region_maps(image_data, rank, world_size)
+        origin = region_data.crop_data["tl_anchor"] if (region_data is not None and region_data.crop_data) else np.zeros(2, int)
+        tiles = []
+        for i in mine:
+            t = crop_image_w_maps(region_data, anchors[i] - origin, patch)
+            t.crop_data = {"tl_anchor": np.array(anchors[i])}              # image coordinates, as merge_patches expects
+            tiles.append(t)
         start = time.perf_counter()
+        sampler, buf, capacity = None, None, mdist.gather_capacity(n_tiles, world_size)
+        if world_size > 1:
+            import torch
+            buf = torch.zeros((capacity + 1, mdist.RECORD), dtype=torch.float64, device=torch.device("cuda", self.device))
+        results: List[List[Rectangle]] = [[] for _ in mine]
         if mine:
-            sampler = TileBatchSampler([tiles[i] for i in mine], self.energy_setup, self.energy_model,
-                                       device=self.device, spec_waves=self.spec_waves)
+            sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device,
+                                       spec_waves=self.spec_waves, use_split_merge=bool(p.get("use_split_merge", False)))
             sampler.init("naive")
-            seed = int(self.rng.integers(0, 2 ** 63 - 1))
-            out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0])
-            for i, res in zip(mine, out):
-                results[i] = res[-1]
+            pack = None
+            if world_size > 1:
+                def pack(ctx):
+                    ctx.pack_detections(mine, np.array([anchors[i] for i in mine]), capacity, buf)
+            out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0], on_device=pack)
+            results = [res[-1] if res else [] for res in out]
+            self.last_intensity = sampler.intensity
             logging.info(f"ran {len(mine)} rjmcmc chains of {total} steps in one launch in "
                          f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
-        if world_size > 1:                      # one all-gather of the fixed-capacity detection buffer
-            pts = [(np.array([[r.x, r.y] for r in results[i]], dtype=float).reshape(-1, 2),
-                    np.array([[r.size, r.ratio, r.angle] for r in results[i]], dtype=float).reshape(-1, 3)) for i in mine]
-            buf = mdist.pack_detections(mine, pts, [None] * len(mine), capacity=1024 * max(1, len(mine)))
-            rec = mdist.all_gather_detections(buf, device=f"cuda:{self.device}")
-            results = [[] for _ in tiles]
-            for r in rec:
-                results[int(r[0])].append(Rectangle(int(r[1]), int(r[2]), size=float(r[3]), ratio=float(r[4]),
-                                                    angle=float(r[5])))
-        logging.info(f"merging {len(tiles)} patches ...")
-        merged = merge_patches(patches=tiles, results=results, original_image=image_data, method="distance",
-                               energy_model=self.energy_model, distance=3, energy_setup=self.energy_setup)
-        scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
-        return merged, scores
+        # what a caller may want to look at afterwards (tests compare single tiles with the CPU oracle)
+        self.last_run = {"seed": seed, "anchors": anchors, "patch": patch, "mine": mine, "tile_results": results,
+                         "total_steps": total, "snapshot_step": snaps[-1] if snaps else total - 1,
+                         "kernel_ms": sampler.kernel_ms if sampler else 0.0}
+        if world_size == 1:
+            logging.info(f"merging {n_tiles} patches ...")
+            merged = merge_patches(patches=tiles, results=results, original_image=region_data, method="distance",
+                                   energy_model=self.energy_model, distance=3, energy_setup=self.energy_setup,
+                                   device=self.device)
+            scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
+            return merged, scores
 
-    def _prefetch_images(self, patch_ids, dataset, subset):
-        """Images with their score maps, one image ahead of the consumer: while the chain kernel of image i runs, a worker
-        thread reads image i+1 and (with ``nets``) runs the two U-Nets and their epilogues on a side stream."""
+        # ---- several ranks: ONE all-gather of the device-packed records (tile id, x, y, size, ratio, angle; image coords)
+        rec = mdist.all_gather_detections(buf, device=f"cuda:{self.device}")
+        points = [Rectangle(int(r[1]), int(r[2]), size=float(r[3]), ratio=float(r[4]), angle=float(r[5])) for r in rec]
+        owned = mdist.tile_owner(n_tiles, world_size)[rec[:, 0].astype(np.int64)] == rank if len(rec) else np.zeros(0, bool)
+        xy = rec[:, 1:3]
+        alive = np.ones(len(points), dtype=bool)
+
+        def score_owned() -> np.ndarray:
+            """Papangelou intensity of this rank's alive points within the configuration of all alive points"""
+            out = np.zeros(len(points))
+            if region_data is None or not np.any(owned & alive):
+                return mdist.all_reduce_owned(out, device=f"cuda:{self.device}")
+            (h, w), (ox, oy) = region_data.shape[:2], origin
+            inside = alive & (xy[:, 0] >= ox) & (xy[:, 0] < ox + h) & (xy[:, 1] >= oy) & (xy[:, 1] < oy + w)
+            idx = np.nonzero(inside)[0]
+            local = [Rectangle(int(xy[k, 0] - ox), int(xy[k, 1] - oy), size=points[k].size, ratio=points[k].ratio,
+                               angle=points[k].angle) for k in idx]
+            unit, pair = self.energy_setup.make_energies(region_data)
+            pts = EPointsSet(local, (h, w), unit, pair, image_data=region_data, device=self.device,
+                             point_capacity=max(1024, len(local) + 64))
+            sc = pts.papangelou_all(energy_combinator=self.energy_model)
+            sel = owned[idx]
+            out[idx[sel]] = sc[sel]
+            return mdist.all_reduce_owned(out, device=f"cuda:{self.device}")
+
+        logging.info(f"merging {n_tiles} patches of {world_size} ranks ...")
+        scores = score_owned()
+        removed = distance_merge(xy, scores, 3)
+        logging.info(f"merge removing {int(removed.sum())} point(s)")
+        alive &= ~removed
+        scores = score_owned() if removed.any() else scores
+        # the order one rank's EPointsSet ends up in: removals swap the last point into the hole (point_set.remove)
+        keep = list(range(len(points)))
+        slot = {k: k for k in keep}
+        for k in np.nonzero(removed)[0]:
+            i, last = slot.pop(int(k)), keep.pop()
+            if last != k:
+                keep[i] = last
+                slot[last] = i
+        keep = np.array(keep, dtype=np.int64)
+        return [points[k] for k in keep], scores[keep]
+
+    def _prefetch_images(self, patch_ids, dataset, subset, rank: int = 0, world_size: int = 1):
+        """Images with the score maps of this rank's region, one image ahead of the consumer: while the chain kernel of
+        image i runs, a worker thread reads image i+1 and (with ``nets``) runs the two U-Nets and their epilogues on a
+        side stream.  Yields (image_data, region_data)."""
         from concurrent.futures import ThreadPoolExecutor
         side = None
         if self.nets is not None:
@@ -254,15 +359,15 @@ class MPPModel:
             side = torch.cuda.Stream(device=self.device)
 
         def load(pid):
+            data = load_image_w_maps(pid, dataset=dataset, subset=subset, position_model=self.position_model,
+                                     shape_model=self.shape_model, nets=self.nets, defer_maps=True)
             if side is None:
-                return load_image_w_maps(pid, dataset=dataset, subset=subset, position_model=self.position_model,
-                                         shape_model=self.shape_model, nets=None)
+                return data, self.region_maps(data, rank, world_size)
             import torch
             with torch.cuda.stream(side):
-                data = load_image_w_maps(pid, dataset=dataset, subset=subset, position_model=self.position_model,
-                                         shape_model=self.shape_model, nets=self.nets)
+                region = self.region_maps(data, rank, world_size)
             side.synchronize()
-            return data
+            return data, region
 
         with ThreadPoolExecutor(max_workers=1) as pool:
             fut = pool.submit(load, patch_ids[0]) if patch_ids else None
@@ -289,8 +394,9 @@ class MPPModel:
                 print(f"{patch_id:04}_results.pkl exists, skipping")
                 continue
             todo.append((patch_id, out_file))
-        for (patch_id, out_file), image_data in zip(todo, self._prefetch_images([t[0] for t in todo], dataset, subset)):
-            merged, scores = self.infer_image(image_data, rank, world)
+        for (patch_id, out_file), (image_data, region_data) in zip(
+                todo, self._prefetch_images([t[0] for t in todo], dataset, subset, rank, world)):
+            merged, scores = self.infer_image(image_data, rank, world, region_data=region_data)
             if rank != 0:
                 continue
             pts = list(merged)

@@ -130,26 +130,36 @@ class TileBatchSampler:
         self.ctx.set_kernels(make_kernels(self.mappings, 1.0, use_split_merge=self.use_split_merge), intensity=self.intensity)
 
     def run(self, total_steps: int, snapshot_steps: Sequence[int], num_samples: int, T0: float, alpha: float,
-            T_target: float, seed: int, chain0: int = 0):
-        """-> per tile, the list of the last ``num_samples`` sampled configurations."""
+            T_target: float, seed: int, chain0: int = 0, on_device=None):
+        """-> per tile, the list of the last ``num_samples`` sampled configurations.
+        ``on_device``: a callable ``f(ctx)`` that takes each sampled state where it lies (e.g.
+        ``ctx.pack_detections`` into an all-gather buffer) instead of copying it to host rectangles."""
         self.ctx.set_schedule(T0, alpha, T_target)
         wanted = list(snapshot_steps)[-num_samples:] if snapshot_steps else []
         samples = [[] for _ in self.tiles]
+
+        def take():
+            if on_device is not None:
+                on_device(self.ctx)
+                return
+            for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
+                samples[i].append(_to_rectangles(*pts))
+
         done = 0
         self.kernel_ms = 0.0
         for t in wanted:                                       # the state after step t = after t+1 steps
-            self.ctx.run(t + 1 - done, seed, chain0)
-            self.kernel_ms += self.ctx.last_kernel_ms()
+            self._run_resumable(t + 1 - done, seed, chain0)
             done = t + 1
-            for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
-                samples[i].append(_to_rectangles(*pts))
+            take()
         if done < total_steps:                                 # the reference keeps stepping to max_iter
-            self.ctx.run(total_steps - done, seed, chain0)
-            self.kernel_ms += self.ctx.last_kernel_ms()
+            self._run_resumable(total_steps - done, seed, chain0)
         if not wanted:
-            for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
-                samples[i].append(_to_rectangles(*pts))
+            take()
         return samples
+
+    def _run_resumable(self, n_steps: int, seed: int, chain0: int):
+        self.ctx.run(n_steps, seed, chain0)
+        self.kernel_ms += self.ctx.last_kernel_ms()
 
 
 def sample_rjmcmc_batch(tiles: Sequence[ImageWMaps], rng: np.random.Generator, num_samples: int, energy_combinator,

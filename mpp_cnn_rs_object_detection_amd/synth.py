@@ -108,3 +108,104 @@ def make_tile(tile: int = 512, n_objects: int = 200, tile_id: int = 0, noise: fl
     gt_xy, gt_marks = make_gt(tile, n_objects, tile_id)
     det, marks = render_maps((tile, tile), gt_xy, gt_marks, noise=noise, noise_seed=77 + tile_id)
     return SynthTile(shape=(tile, tile), det=det, marks=marks, gt_xy=gt_xy, gt_marks=gt_marks)
+
+
+# ---- the IMAGE recipe of the reference's synthetic dataset (BASELINE config 5) ------------------------------------
+def _rect_corners(x, y, size, ratio, angle) -> np.ndarray:
+    """(4, 2) corners of Rectangle(x, y, size, ratio, angle).poly_coord (``base/shapes/rectangle.py:20-31,69-100``)"""
+    length = 2.0 * size / (1.0 + ratio)
+    width = ratio * length
+    hs, hl = length / 2.0, width / 2.0
+    local = np.array([[hs, hl], [hs, -hl], [-hs, -hl], [-hs, hl]])
+    a = angle + np.pi / 2
+    c, s = np.cos(a), np.sin(a)
+    return local @ np.array([[c, -s], [s, c]]).T + np.array([x, y], dtype=float)
+
+
+def _quads_overlap(a: np.ndarray, b: np.ndarray) -> bool:
+    """Two convex quads share area  <=>  none of the 8 edge normals separates them (separating-axis theorem)."""
+    for q in (a, b):
+        e = np.roll(q, -1, axis=0) - q
+        normals = np.stack([-e[:, 1], e[:, 0]], axis=1)
+        pa, pb = a @ normals.T, b @ normals.T
+        if np.any((pa.max(axis=0) <= pb.min(axis=0)) | (pb.max(axis=0) <= pa.min(axis=0))):
+            return False
+    return True
+
+
+def make_scene_image(shape: Tuple[int, int] = (256, 256), n_rect: int = 230, noise: float = 0.02, seed: int = 0):
+    """Restates ``make_synth`` of the reference's ``data/make_synth_data.py:16-47``: ``n_rect`` rectangles with
+    centre ~ U(image), size ~ N(8, 1), ratio ~ clip(N(0.5, 0.1), 0.1, 1), angle ~ U(0, pi), drawn in that order from
+    one generator; a rectangle is kept if it overlaps none of those kept before it; the image is 0.5 everywhere,
+    each kept rectangle filled with choice{0, 1} + N(0, 0.1), clipped, plus pixel noise N(0, ``noise``), clipped.
+    (The reference tests overlap with shapely and rasterises with ``skimage.draw.polygon``, both absent here: the
+    separating-axis test and a pixel-centre-inside test stand in; overlap candidates come from a coarse grid so that
+    a 4096 x 4096 scene with ~5 000 rectangles -- BASELINE config 5 -- takes seconds.)
+    Returns (image [H, W, 3] float32, gt_xy [N, 2] int32, gt_marks [N, 3] float64)."""
+    rng = np.random.default_rng(seed)
+    H, W = shape
+    rects = []
+    for _ in range(n_rect):
+        x = int(rng.integers(0, H)); y = int(rng.integers(0, W))
+        size = float(rng.normal(8, 1.0))
+        ratio = float(np.clip(rng.normal(0.5, 0.1), 0.1, 1))
+        angle = float(rng.uniform(0, np.pi))
+        rects.append((x, y, size, ratio, angle))
+    cell = 32
+    grid: dict = {}
+    kept, kept_poly = [], []
+    for r in rects:
+        poly = _rect_corners(*r)
+        ci, cj = r[0] // cell, r[1] // cell
+        ok = True
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                for k in grid.get((ci + di, cj + dj), ()):
+                    if _quads_overlap(poly, kept_poly[k]):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            if not ok:
+                break
+        if ok:
+            grid.setdefault((ci, cj), []).append(len(kept))
+            kept.append(r)
+            kept_poly.append(poly)
+    img = np.ones((H, W, 3)) * 0.5
+    for r, poly in zip(kept, kept_poly):
+        value = float(rng.choice([0, 1.0])) + float(rng.normal(0, 0.1))
+        x0, x1 = max(0, int(np.floor(poly[:, 0].min()))), min(H, int(np.ceil(poly[:, 0].max())) + 1)
+        y0, y1 = max(0, int(np.floor(poly[:, 1].min()))), min(W, int(np.ceil(poly[:, 1].max())) + 1)
+        if x1 <= x0 or y1 <= y0:
+            continue
+        xx, yy = np.mgrid[x0:x1, y0:y1]
+        e = np.roll(poly, -1, axis=0) - poly
+        side = [(e[k, 0] * (yy - poly[k, 1]) - e[k, 1] * (xx - poly[k, 0])) for k in range(4)]
+        inside = np.all(np.stack(side) >= 0, axis=0) | np.all(np.stack(side) <= 0, axis=0)
+        img[x0:x1, y0:y1][inside] = value
+    img = np.clip(img, 0, 1)
+    img = img + rng.normal(0, noise, size=img.shape)
+    img = np.clip(img, 0, 1).astype(np.float32)
+    gt_xy = np.array([[r[0], r[1]] for r in kept], dtype=np.int32).reshape(-1, 2)
+    gt_marks = np.array([[r[2], r[3], r[4]] for r in kept], dtype=np.float64).reshape(-1, 3)
+    return img, gt_xy, gt_marks
+
+
+def make_mosaic(n_side: int = 4, tile: int = 512, n_objects: int = 200, first_tile_id: int = 0, noise: float = 0.0):
+    """BASELINE config 4: an ``n_side`` x ``n_side`` mosaic of the synthetic tile generator:
+    -> det [S, S] f32, marks 3 x [S, S, 32] f32, gt_xy [N, 2], gt_marks [N, 3] with S = n_side * tile."""
+    S = n_side * tile
+    det = np.zeros((S, S), np.float32)
+    marks = [np.zeros((S, S, N_CLASSES), np.float32) for _ in range(3)]
+    xy, mk = [], []
+    for i in range(n_side):
+        for j in range(n_side):
+            t = make_tile(tile, n_objects, tile_id=first_tile_id + i * n_side + j, noise=noise)
+            sl = (slice(i * tile, (i + 1) * tile), slice(j * tile, (j + 1) * tile))
+            det[sl] = t.det
+            for k in range(3):
+                marks[k][sl] = t.marks[k]
+            xy.append(t.gt_xy + np.array([i * tile, j * tile], dtype=np.int32))
+            mk.append(t.gt_marks)
+    return det, marks, np.concatenate(xy), np.concatenate(mk)

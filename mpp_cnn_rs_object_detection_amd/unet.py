@@ -171,6 +171,18 @@ def load_torch_model(module: nn.Module, model_dir: str) -> bool:
     return True
 
 
+#: receptive-field radius of the three-level U-Net (two 3x3 convolutions per level: 2 + 4 + 8 + 16 + 8 + 4 + 2 = 44 px
+#: at full resolution) plus the one-pixel stencil of the divergence (torch_div.py:8-43), rounded up to a multiple of 8
+HALO = 48
+
+
+def halo_crop(region, shape, halo: int = HALO, align: int = 8):
+    """(x0, x1, y0, y1) -> the crop the nets must see to reproduce the maps of that region (see ``infer_region``)"""
+    x0, x1, y0, y1 = (int(v) for v in region)
+    H, W = int(shape[0]), int(shape[1])
+    return (max(0, x0 - halo) // align * align, min(H, x1 + halo), max(0, y0 - halo) // align * align, min(W, y1 + halo))
+
+
 class ScoreMapNets:
     """PosNet + ShapeNet inference on one GPU with the fused HIP epilogues."""
 
@@ -298,6 +310,21 @@ class ScoreMapNets:
                 pos_out = self.pos(x)
                 logits = self.shp(x)
         return self._epilogues(pos_out, logits, H, W)
+
+    @torch.no_grad()
+    def infer_region(self, image, region) -> Tuple[Tensor, List[Tensor]]:
+        """Score maps of the image region ``(x0, x1, y0, y1)`` only: the nets run on the region plus ``HALO`` pixels
+        (origin rounded down to a multiple of 2**depth so that pooling and the bottom/right zero padding of
+        ``pad_before_infer`` fall as they do on the whole image, crop clamped to the image so that image borders
+        keep their reflect padding / one-sided differences); everything an interior crop border can influence lies
+        inside the halo, which is cut off.  Up to the convolution library's choice of algorithm per shape the result
+        equals ``infer(image)[region]`` -- this is how a rank of a multi-GPU run gets the maps of its own tiles
+         without a forward over the whole image."""
+        x0, x1, y0, y1 = (int(v) for v in region)
+        cx0, cx1, cy0, cy1 = halo_crop(region, tuple(image.shape[:2]), align=2 ** self.pos.backbone.depth)
+        det, marks = self.infer(image[cx0:cx1, cy0:cy1])
+        sl = (slice(x0 - cx0, x1 - cx0), slice(y0 - cy0, y1 - cy0))
+        return det[sl], [m[sl] for m in marks]
 
     def _epilogues(self, pos_out: Tensor, logits: List[Tensor], H: int, W: int) -> Tuple[Tensor, List[Tensor]]:
         pos_out = pos_out[0].float().contiguous()

@@ -103,6 +103,11 @@ def lib():
         L.orc_run.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
         L.orc_step_index.restype = C.c_int64
         L.orc_step_index.argtypes = [C.c_void_p]
+        L.orc_follow.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_step_index.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_temperature.restype = C.c_double
+        L.orc_temperature.argtypes = [C.c_void_p]
+        L.orc_replay_forced.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_philox.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_overlap.restype = C.c_double
         L.orc_overlap.argtypes = [C.c_void_p, C.c_void_p]
@@ -220,6 +225,36 @@ class Oracle:
         if rc != 0:
             raise RuntimeError(f"replay failed at step {-rc - 1}: target slot out of range")
         return out
+
+    def replay_forced(self, tape: np.ndarray, accept: np.ndarray):
+        """replay with the accept decision of every step imposed (tests: resync after a tie within the dE tolerance)"""
+        tape = np.ascontiguousarray(tape, dtype=PROPOSAL_DTYPE)
+        acc = np.ascontiguousarray(accept, dtype=np.int32)
+        if lib().orc_replay_forced(self._h, len(tape), _ptr(tape), _ptr(acc), None) != 0:
+            raise RuntimeError("forced replay: target slot out of range")
+
+    def follow(self, tape: np.ndarray, seed: int, chain: int = 0):
+        """Perform the tape's proposals with the oracle's own decisions; returns (step records, the proposals the oracle
+        would have drawn itself at each step) -- see ``orc_follow``."""
+        tape = np.ascontiguousarray(tape, dtype=PROPOSAL_DTYPE)
+        out, native = np.zeros(len(tape), STEPOUT_DTYPE), np.zeros(len(tape), PROPOSAL_DTYPE)
+        rc = lib().orc_follow(self._h, len(tape), int(seed), int(chain), _ptr(tape), _ptr(out), _ptr(native))
+        if rc != 0:
+            raise RuntimeError(f"follow failed at step {-rc - 1}: target slot out of range")
+        return out, native
+
+    def step_index(self) -> int:
+        return int(lib().orc_step_index(self._h))
+
+    def save(self):
+        """(points, step index, temperature) -- enough to come back to this moment of the chain"""
+        return self.get_points(), self.step_index(), float(lib().orc_temperature(self._h))
+
+    def restore(self, saved, alpha: float, T_target: float = 0.0):
+        (xy, marks), step, T = saved
+        self.set_points(xy, marks)
+        lib().orc_set_step_index(self._h, int(step))
+        self.set_temperature(T, alpha, T_target)
 
     def run(self, n_steps: int, seed: int, chain: int = 0, trace: bool = False):
         out = np.zeros(n_steps if trace else 0, STEPOUT_DTYPE)

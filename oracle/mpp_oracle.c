@@ -45,6 +45,7 @@ struct orc_ctx {
   double det_sum, *cdf;       /* shape_samplers.py:87 (normalised detection map) + its cdf */
   double T, alpha, T_target;
   int64_t step;
+  int forced;            /* -1: Metropolis test; 0 / 1: decision imposed by orc_replay_forced */
   /* scratch */
   int *mark; int mark_gen;
 };
@@ -372,7 +373,7 @@ orc_ctx *orc_create(int H, int W, const float *det, const float *m0, const float
   for (size_t i = 0; i < hw; ++i) { s += (double)c->det[i]; c->cdf[i] = s; }
   c->det_sum = s;
   if (s > 0) for (size_t i = 0; i < hw; ++i) c->cdf[i] /= s;
-  c->T = 1.0; c->alpha = 1.0; c->T_target = 0.0; c->step = 0;
+  c->T = 1.0; c->alpha = 1.0; c->T_target = 0.0; c->step = 0; c->forced = -1;
   return c;
 }
 void orc_destroy(orc_ctx *c) {
@@ -404,6 +405,8 @@ int orc_get_points(orc_ctx *c, int cap, int32_t *xy, double *marks) {
 }
 int orc_count(orc_ctx *c) { return c->n; }
 int64_t orc_step_index(orc_ctx *c) { return c->step; }
+void orc_set_step_index(orc_ctx *c, int64_t step) { c->step = step; }
+double orc_temperature(orc_ctx *c) { return c->T; }
 void orc_set_temperature(orc_ctx *c, double T, double alpha, double T_target) {
   c->T = T; c->alpha = alpha; c->T_target = T_target;
 }
@@ -781,6 +784,7 @@ static void do_step(orc_ctx *c, const orc_proposal *pr, orc_step_out *out) {
   if (n_add || n_rem) dE = delta_rects(c, n_rem, rem, n_add, add);
   double log_alpha = (-dE / c->T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN);
   int accepted = log(pr->u_accept + EPS_GREEN) < log_alpha;
+  if (c->forced >= 0) accepted = c->forced;      /* orc_replay_forced: a decision taken elsewhere (test resync) */
   if (accepted) {
     /* canonical slots: the (first) added point takes the (first) removed point's slot, a second added point is
      * appended, a second removed point is swap-removed */
@@ -802,6 +806,41 @@ int orc_replay(orc_ctx *c, int n, const orc_proposal *tape, orc_step_out *out) {
   for (int i = 0; i < n; ++i) {
     if (tape[i].target >= c->n) return -(i + 1);
     if (tape[i].kernel == ORC_K_MERGE && tape[i].param_id >= 0 && (tape[i].param_id >= c->n || tape[i].param_id == tape[i].target)) return -(i + 1);
+    do_step(c, &tape[i], out ? &out[i] : NULL);
+  }
+  return 0;
+}
+/* replay with the accept decision of every step given (accept[i] != 0): puts the oracle into the state of a chain whose
+ * decisions were taken elsewhere -- used by the tests to re-synchronise after a tie within the dE tolerance */
+int orc_replay_forced(orc_ctx *c, int n, const orc_proposal *tape, const int32_t *accept, orc_step_out *out) {
+  int rc = 0;
+  for (int i = 0; i < n && rc == 0; ++i) {
+    if (tape[i].target >= c->n) { rc = -(i + 1); break; }
+    c->forced = accept[i] ? 1 : 0;
+    do_step(c, &tape[i], out ? &out[i] : NULL);
+  }
+  c->forced = -1;
+  return rc;
+}
+/* Follow a tape while drawing natively: at every step the oracle draws ITS proposal from Philox and its current state
+ * (recorded in `native`, never applied) and then performs the step with the tape's proposal and its own Metropolis
+ * decision.  With the tape of a kernel run this keeps the two states bit-identical (the device's log / sincos differ
+ * from libm's in the last place, so natively drawn Gaussian marks do too), which separates the two parity questions:
+ * are the proposals the same (native vs tape), and are dE / the decisions the same given the same proposal. */
+int orc_follow(orc_ctx *c, int n, uint64_t seed, uint32_t chain, const orc_proposal *tape, orc_step_out *out,
+               orc_proposal *native) {
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int i = 0; i < n; ++i) {
+    uint32_t w[8];
+    uint64_t s = (uint64_t)c->step;
+    for (uint32_t b = 0; b < 2; ++b) {
+      uint32_t ctr[4] = {(uint32_t)s, (uint32_t)(s >> 32), b, chain};
+      orc_philox(ctr, key, w + 4 * b);
+    }
+    orc_proposal pr;
+    draw_proposal(c, w, &pr, key, s, chain);
+    if (native) native[i] = pr;
+    if (tape[i].target >= c->n) return -(i + 1);
     do_step(c, &tape[i], out ? &out[i] : NULL);
   }
   return 0;

@@ -132,7 +132,14 @@ int orc_replay(orc_ctx *c, int n, const orc_proposal *tape, orc_step_out *out);
 /* native chain: proposals drawn from Philox4x32-10(key=seed, ctr=(step, block, chain)) */
 int orc_run(orc_ctx *c, int64_t n_steps, uint64_t seed, uint32_t chain, orc_step_out *out_or_null,
             orc_proposal *props_or_null);
+/* follow `tape` (its proposals, the oracle's own decisions) while recording the proposals the oracle would draw itself */
+int orc_follow(orc_ctx *c, int n, uint64_t seed, uint32_t chain, const orc_proposal *tape, orc_step_out *out_or_null,
+               orc_proposal *native_or_null);
 int64_t orc_step_index(orc_ctx *c);
+void orc_set_step_index(orc_ctx *c, int64_t step);
+double orc_temperature(orc_ctx *c);
+/* replay with every accept decision imposed (test resync after a tie within the dE tolerance) */
+int orc_replay_forced(orc_ctx *c, int n, const orc_proposal *tape, const int32_t *accept, orc_step_out *out_or_null);
 void orc_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double orc_overlap(const double r1[5], const double r2[5]);
 /* greedy distance NMS init (sample_rjmcmc.py:23-35, utils/nms.py:68-110); returns count */

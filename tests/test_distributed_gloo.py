@@ -27,6 +27,16 @@ WORKER = textwrap.dedent("""
     expect = np.concatenate([np.concatenate([np.full((len(p[0]), 1), t), p[0], p[1], p[2][:, None]], axis=1)
                              for t, p in enumerate(all_pts)])
     ok = rec.shape == expect.shape and np.array_equal(rec, expect)
+    # blocks are contiguous and of different sizes (5 tiles on 2 ranks: 2 + 3), the buffer capacity is not
+    ok = ok and mine == ([0, 1] if rank == 0 else [2, 3, 4]) and mdist.gather_capacity(n_tiles, world, per_tile=16) == 48
+    # scores: every rank contributes the entries of its own tiles' points, one all-reduce combines them exactly
+    owner = mdist.tile_owner(n_tiles, world)[rec[:, 0].astype(int)]
+    scores = np.where(owner == rank, rec[:, 6], 0.0)
+    ok = ok and np.array_equal(mdist.all_reduce_owned(scores), rec[:, 6])
+    # a device-style tensor buffer goes through the same gather
+    import torch
+    rec2 = mdist.all_gather_detections(torch.from_numpy(buf))
+    ok = ok and np.array_equal(rec2, expect)
     print(json.dumps({"rank": rank, "world": world, "mine": mine, "ok": bool(ok), "n": int(len(rec))}))
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()

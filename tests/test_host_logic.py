@@ -100,8 +100,13 @@ def test_shapes_and_mappings():
 
 
 def test_tile_sharding_and_detection_packing():
-    assert mdist.shard_tiles(10, 1, 4) == [1, 5, 9]
-    assert sorted(sum([mdist.shard_tiles(16, r, 8) for r in range(8)], [])) == list(range(16))
+    # contiguous blocks (a rank's tiles form one compact image region), sizes differing by at most one
+    assert mdist.shard_tiles(10, 1, 4) == [2, 3, 4] and mdist.shard_tiles(9, 0, 2) == [0, 1, 2, 3]
+    assert sum([mdist.shard_tiles(16, r, 8) for r in range(8)], []) == list(range(16))
+    assert mdist.shard_tiles(3, 0, 8) == [] and mdist.shard_tiles(3, 5, 8) == [1] and sum([mdist.shard_tiles(3, r, 8) for r in range(8)], []) == [0, 1, 2]
+    assert mdist.tile_owner(9, 2).tolist() == [0, 0, 0, 0, 1, 1, 1, 1, 1]
+    # the gather buffer has the same capacity on every rank, whatever the rank owns (9 tiles on 2 / 8 ranks)
+    assert mdist.gather_capacity(9, 2) == 5 * 1024 and mdist.gather_capacity(9, 8) == 2 * 1024
     pts = [(np.array([[1, 2], [3, 4]]), np.array([[5., .5, 1.], [6., .6, 2.]])), (np.zeros((0, 2)), np.zeros((0, 3)))]
     buf = mdist.pack_detections([3, 7], pts, [np.array([.9, .8]), np.zeros(0)], capacity=8)
     rec = mdist.unpack_detections(buf[None])

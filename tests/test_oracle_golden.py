@@ -95,3 +95,41 @@ def test_delta_cases(tag, setup_name):
         e1 = o2.total_energy()
         assert e1 == pytest.approx(float(e1_ref), rel=1e-6, abs=5e-6)
         assert abs(d - (e1 - e0)) < 1e-8    # the reference's own criterion, test_perturbation_sampler.py:99
+
+
+def test_follow_and_forced_replay_reproduce_a_native_chain():
+    """The test-side resync tools of the oracle: following its own tape gives the same records and draws the same
+    proposals; a forced replay with the recorded decisions lands on the same state; a forced replay with the opposite
+    decision for one step does not."""
+    import oracle
+    from helpers import model_for
+    from mpp_cnn_rs_object_detection_amd import kernels, mappings, synth
+    t = synth.make_tile(96, 18, tile_id=21, noise=0.1)
+    setup, comb, model = model_for("legacy")
+    maps = mappings.default_mappings()
+    o = oracle.Oracle(t.shape, t.det, t.marks, model, kernels.make_kernels(maps, 1.0))
+    xy, mk = o.naive_detection(setup.detection_threshold, 6.0)
+    kd = kernels.make_kernels(maps, float(max(1, len(xy))))
+    o = oracle.Oracle(t.shape, t.det, t.marks, model, kd)
+    o.set_points(xy, mk)
+    o.set_temperature(1.0, 0.998, 0.0)
+    start = o.save()
+    out, props = o.run(1500, 7, chain=3, trace=True)
+    end_xy, end_m = o.get_points()
+    o.restore(start, 0.998)
+    out2, native = o.follow(props, 7, chain=3)
+    assert np.array_equal(out2, out) and np.array_equal(native, props) and o.step_index() == 1500
+    o.restore(start, 0.998)
+    o.replay_forced(props, out["accepted"])
+    xy2, m2 = o.get_points()
+    assert np.array_equal(xy2, end_xy) and np.array_equal(m2, end_m)
+    k = int(np.nonzero((out["accepted"] > 0) & (props["kernel"] == 4))[0][0])       # an accepted translation
+    flipped = out["accepted"].copy()
+    flipped[k] = 0
+    o.restore(start, 0.998)
+    o.replay_forced(props[:k + 1], flipped[:k + 1])
+    xy3, _ = o.get_points()
+    o.restore(start, 0.998)
+    o.replay_forced(props[:k + 1], out["accepted"][:k + 1])
+    xy4, _ = o.get_points()
+    assert not np.array_equal(xy3, xy4)
