@@ -110,8 +110,8 @@ def distance_merge(xy: np.ndarray, scores: np.ndarray, distance: float) -> np.nd
     """The dedupe rule of the reference's ``merge_patches(method='distance')`` (``data_loaders.py:140-159``) as a
     function of the aggregated points alone: walking the points in order, every not-yet-removed point keeps, among
     the not-yet-removed points within ``distance`` of it (itself included), only the one with the best Papangelou
-    intensity.  Returns the mask of removed points.  Deterministic in its inputs, so ranks that hold the same
-    gathered points and scores take the same decision."""
+    intensity (ties to 1e-9: the first).  Returns the mask of removed points.  Deterministic in its inputs, so ranks
+    that hold the same gathered points and scores take the same decision."""
     n = len(xy)
     removed = np.zeros(n, dtype=bool)
     if n == 0:
@@ -125,7 +125,12 @@ def distance_merge(xy: np.ndarray, scores: np.ndarray, distance: float) -> np.nd
         near = np.array(sorted(j for j in balls[i] if not removed[j]), dtype=np.int64)
         if len(near) == 0:
             continue
-        best = near[np.argmax(scores[near])]
+        # the best one; scores equal to 1e-9 count as a tie and the first point (tile order) wins.  (Two tiles that
+        # overlap report the same object twice, often with identical energies; the reference breaks such ties by the
+        # iteration order of a Python set.  The tolerance keeps the decision independent of the last-place differences
+        # between scores computed on different ranks' regions.)
+        sc = scores[near]
+        best = near[np.nonzero(sc >= sc.max() - 1e-9 * abs(sc.max()))[0][0]]
         removed[near] = True
         removed[best] = False
     return removed

@@ -208,9 +208,11 @@ class MPPModel:
             json.dump(d, f, indent=1)
 
     # ------------------------------------------------------------------------------------------------
-    #: a rank needs score maps on its tiles plus this margin: every point a detection of one of its tiles interacts
-    #: with (pair energies reach 32 px, prior_energies.py / energy_graph.py:26-29) then has its unit energies available
-    SCORE_MARGIN = 32
+    #: a rank keeps its tiles plus this margin.  The Papangelou intensity of a point u changes the energy of every
+    #: neighbour v within the interaction radius (32 px, prior_energies.py / energy_graph.py:26-29), and v's energy holds
+    #: max / min reductions over ITS neighbours w: everything within two radii of u must be part of the configuration
+    #: the rank scores u in, and the unit energies of every v need the score maps there
+    SCORE_MARGIN = 64
 
     def tile_layout(self, shape):
         """(patch size, anchors) of an image: the reference's overlapping 256-px tiles (``mpp_model.py:231-248``)"""

@@ -431,8 +431,174 @@ def make_perturbation_golden():
     print("wrote perturbations_golden.npz")
 
 
+
+def make_host_golden():
+    """The host halves the sampler sits between, run in the REFERENCE on fixed inputs:
+
+    * ``crop_image_w_maps`` + ``merge_patches`` (models/mpp/data_loaders.py:74-161) on a toy image cut into its two
+      overlapping tiles, with hand-placed detections (pairs of duplicates across the tile seam, isolated so that the
+      outcome does not depend on the reference's set iteration order);
+    * one loss value of the ordering criterion (train_energy_combination/train_ordering_criterion.py:101-118) for fixed
+      perturbations and fixed parameters of both torch weight models (combination/{logistic,hierarchical}.py);
+    * the calibration functions (calibration/energy_calibration.py:19-185) on two tiles.
+    """
+    import torch
+    from models.mpp.data_loaders import crop_image_w_maps, merge_patches
+    from models.mpp.perturbation_sampler import sample_multiple_kernel_perturbations
+    from models.mpp.train_energy_combination.train_ordering_criterion import EnergyComputeTorch
+    from models.mpp.energies.combination.logistic import LogisticEnergyModel
+    from models.mpp.energies.combination.hierarchical import HierarchicalEnergyModel
+    from models.mpp.calibration import energy_calibration as ec
+    out = {}
+
+    # ---- (1) crop + merge ----------------------------------------------------------------------------------------
+    H, W = 256, 300                                        # one row of two tiles, anchors (0, 0) and (0, 44)
+    gt_xy, gt_marks = synth.make_gt(256, 60, tile_id=40)
+    ex_xy, ex_marks = synth.make_gt(256, 20, tile_id=41)
+    sel = ex_xy[:, 1] < 40
+    gt_xy = np.concatenate([gt_xy, ex_xy[sel] + np.array([0, 256])]).astype(np.int32)
+    gt_marks = np.concatenate([gt_marks, ex_marks[sel]])
+    det, marks = synth.render_maps((H, W), gt_xy, gt_marks, noise=0.1, noise_seed=9)
+    b = 2 * gt_marks[:, 0] / (1 + gt_marks[:, 1])
+    labels = {"centers": gt_xy.astype(np.int64), "parameters": np.stack([b * gt_marks[:, 1], b, gt_marks[:, 2]], axis=1),
+              "categories": np.array(["small-vehicle"] * len(gt_xy)), "difficult": np.zeros(len(gt_xy), dtype=np.int64)}
+    from models.mpp.data_loaders import labels_to_rectangles
+    image = ImageWMaps(name="0000", shape=(H, W), image=np.zeros((H, W, 3), np.float32), detection_map=det,
+                       param_dist_maps=[m.copy() for m in marks], mappings=mappings(), param_names=PARAM_NAMES,
+                       labels=labels, gt_config=labels_to_rectangles(labels, Rectangle.PARAMETERS))
+    anchors = [np.array([0, 0]), np.array([0, 44])]
+    patches = [crop_image_w_maps(image, a, 256) for a in anchors]
+    for k, pt in enumerate(patches):
+        out[f"crop{k}_centers"] = np.asarray(pt.labels["centers"], dtype=np.int64).reshape(-1, 2)
+        out[f"crop{k}_parameters"] = np.asarray(pt.labels["parameters"], dtype=np.float64).reshape(-1, 3)
+        out[f"crop{k}_gt"] = np.array([rect_row(r) for r in pt.gt_config], dtype=float).reshape(-1, 5)
+        out[f"crop{k}_det_sum"] = float(np.sum(pt.detection_map, dtype=np.float64))
+        out[f"crop{k}_shape"] = np.array(pt.shape)
+    # detections per tile: the ground truth each tile sees, jittered; in the 212-px overlap both tiles report the object
+    # (second copy moved by <= 2 px: within the merge distance of 3), plus two false positives far from everything
+    rng = np.random.default_rng(5)
+    results = []
+    for k, pt in enumerate(patches):
+        res = []
+        for r in pt.gt_config:
+            if k == 1 and rng.random() < 0.3:
+                continue                                   # tile 1 misses some
+            dx, dy = (0, 0) if k == 0 else (int(rng.integers(-1, 2)), int(rng.integers(-1, 2)))
+            res.append(Rectangle(int(np.clip(r.x + dx, 0, 255)), int(np.clip(r.y + dy, 0, 255)),
+                                 size=float(r.size + (0.0 if k == 0 else rng.normal(0, 0.3))), ratio=float(r.ratio),
+                                 angle=float((r.angle + (0.0 if k == 0 else rng.normal(0, 0.1))) % np.pi)))
+        results.append(res)
+    s, c = hrc_setup()
+    for k, res in enumerate(results):
+        out[f"merge_in{k}"] = np.array([rect_row(r) for r in res], dtype=float).reshape(-1, 5)
+    merged = merge_patches(patches=patches, results=results, original_image=image, energy_model=c, method="distance",
+                           energy_setup=s, distance=3)
+    mpts = list(merged)
+    out["merge_out"] = sorted_rows_np([rect_row(r) for r in mpts])
+    uec, pec = s.make_energies(image_data=image)
+    full = EPointsSet(points=mpts, support_shape=image.shape, unit_energies_constructors=uec, pair_energies_constructors=pec)
+    sc = {tuple(rect_row(r)): float(full.papangelou(r, energy_combinator=c, remove_u_from_point_set=True)) for r in mpts}
+    out["merge_scores"] = np.array([sc[tuple(r)] for r in out["merge_out"]])
+    out["merge_det"], out["merge_gt_xy"], out["merge_gt_marks"] = det, gt_xy, gt_marks
+    print(f"merge: {sum(len(r) for r in results)} detections in, {len(mpts)} out")
+
+    # ---- (2) ordering criterion --------------------------------------------------------------------------------------
+    for tag, (setup, _), model in (("log", log_setup(), None), ("hrc", hrc_setup(), None)):
+        tile = synth.make_tile(96, 18, tile_id=42, noise=0.2)
+        d = image_data_from(tile)
+        uec, pec = setup.make_energies(image_data=d)
+        d.gt_config_set = EPointsSet(points=d.gt_config, support_shape=d.shape[:2], unit_energies_constructors=uec,
+                                     pair_energies_constructors=pec)
+        perts = sample_multiple_kernel_perturbations(d, energy_setup=setup, rng=np.random.default_rng(8), iter_per_point=0.5,
+                                                     n_samples=12, return_perturbations=True, aggregate_pert=True)
+        if tag == "log":
+            wm = LogisticEnergyModel(use_bias=True, energy_names=setup.energy_names)
+            with torch.no_grad():
+                wm.weights.copy_(torch.tensor([1.5, 0.4, -0.3, 0.8, 2.0, 0.6, 0.2, 1.1]))
+                wm.bias.copy_(torch.tensor(0.25))
+            params = {"weights": wm.weights.detach().numpy().astype(np.float64), "bias": 0.25}
+        else:
+            wm = HierarchicalEnergyModel(threshold=0.0)
+            with torch.no_grad():
+                wm.data_prior_weight.copy_(torch.tensor([0.3, -0.2]))
+                wm.data_weight.copy_(torch.tensor([0.9, 0.1]))
+                wm.prior_weight.copy_(torch.tensor([0.5, -0.4, 0.2]))
+            params = {"data_prior_weight": np.array([0.3, -0.2]), "data_weight": np.array([0.9, 0.1]),
+                      "prior_weight": np.array([0.5, -0.4, 0.2])}
+        comb = EnergyComputeTorch(weights_model=wm, energy_names=setup.energy_names)
+        deltas = []
+        for pert in perts:
+            delta = d.gt_config_set.energy_delta(p=pert, energy_combinator=comb)
+            if delta != 0.0:
+                deltas.append(delta)
+        loss = -torch.mean(torch.stack(deltas))
+        loss.backward()
+        grads = {k: v.grad.detach().numpy().astype(np.float64) for k, v in wm.named_parameters() if v.grad is not None}
+        out[f"oc_{tag}_loss"] = float(loss.detach())
+        out[f"oc_{tag}_deltas"] = np.array([float(x.detach()) for x in deltas])
+        out[f"oc_{tag}_n_pert"] = len(perts)
+        for k, v in params.items():
+            out[f"oc_{tag}_param_{k}"] = np.asarray(v)
+        for k, v in grads.items():
+            out[f"oc_{tag}_grad_{k}"] = v
+        out[f"oc_{tag}_add_flat"] = np.array([rect_row(q) for pp in perts for q in pp.addition], dtype=float).reshape(-1, 5)
+        out[f"oc_{tag}_add_len"] = np.array([len(pp.addition) for pp in perts])
+        out[f"oc_{tag}_rem_flat"] = np.array([rect_row(q) for pp in perts for q in pp.removal], dtype=float).reshape(-1, 5)
+        out[f"oc_{tag}_rem_len"] = np.array([len(pp.removal) for pp in perts])
+        print(f"ordering criterion {tag}: {len(deltas)} non-zero deltas of {len(perts)}, loss {float(loss):.6f}")
+
+    # ---- (3) calibration -------------------------------------------------------------------------------------------------
+    tiles = [synth.make_tile(128, 30, tile_id=43 + k, noise=0.25) for k in range(2)]
+    datas = [image_data_from(t) for t in tiles]
+    for t, dd in zip(tiles, datas):                       # noisy detection maps so that the best threshold is interior
+        nrng = np.random.default_rng(3)
+        dd.detection_map = np.clip(t.det + 0.25 * nrng.random(t.det.shape, dtype=np.float32), 0, 1).astype(np.float32)
+    out["cal_threshold"] = float(ec.calibrate_detection_threshold([dd.detection_map for dd in datas], [dd.labels for dd in datas]))
+    orig_lr = ec.LogisticRegression
+
+    def lr_compat(penalty="l2", **kw):                    # scikit-learn >= 1.2 spells penalty='none' as penalty=None
+        return orig_lr(penalty=None if penalty == "none" else penalty, **kw)
+    ec.LogisticRegression = lr_compat
+    try:
+        coefs, icpts = ec.calibrate_param_dists([dd.param_dist_maps for dd in datas], [dd.gt_config for dd in datas],
+                                                mappings=mappings(), param_names=PARAM_NAMES, rng=np.random.default_rng(4))
+    finally:
+        ec.LogisticRegression = orig_lr
+    out["cal_coefs"], out["cal_intercepts"] = np.array(coefs, dtype=float), np.array(icpts, dtype=float)
+    mn, mx = ec.calibrate_min_area([dd.gt_config for dd in datas])
+    out["cal_min_area"], out["cal_max_area"] = float(mn), float(mx)
+    out["cal_tile_ids"] = np.array([43, 44])
+    print(f"calibration: threshold {out['cal_threshold']:.4f}, coefs {coefs}, area [{mn:.3f}, {mx:.3f}]")
+    np.savez_compressed(os.path.join(HERE, "host_golden.npz"), **out)
+    print("wrote host_golden.npz", os.path.getsize(os.path.join(HERE, "host_golden.npz")) // 1024, "KiB")
+
+
+def sorted_rows_np(rows):
+    a = np.asarray(rows, dtype=float).reshape(-1, 5)
+    return a[np.lexsort(a.T[::-1])] if len(a) else a
+
+
+def make_tapes_256():
+    """BASELINE config 1: a 256x256 tile / 50 objects, 1 000 iterations of the reference sampler with
+    the shipped schedules of mpp_hrcM and mpp_log (T0 = 1, alpha = 0.999), plus a warm mpp_hrcM chain (T0 = 0.02) in which
+    births and moves get accepted."""
+    t = synth.make_tile(256, 50, tile_id=0)
+    s, c = hrc_setup()
+    params = dict(init_temperature=1.0, target_temperature=0.0, alpha_t=0.999, burn_in=744, samples_interval=128)
+    save_tape("tape_hrc_256.npz", t, record_tape(t, s, c, seed=6, rjmcmc_params=params), "legacy", params,
+              extra=dict(noise=0.0, noise_seed=77))
+    s, c = log_setup()
+    params = dict(init_temperature=1.0, target_temperature=0.0, alpha_t=0.999, burn_in=998, samples_interval=1)
+    save_tape("tape_log_256.npz", t, record_tape(t, s, c, seed=7, rjmcmc_params=params), "no-calibration", params,
+              extra=dict(noise=0.0, noise_seed=77))
+    s, c = hrc_setup()
+    params = dict(init_temperature=0.02, target_temperature=0.0, alpha_t=0.999, burn_in=744, samples_interval=128)
+    save_tape("tape_hrc_256_warm.npz", t, record_tape(t, s, c, seed=8, rjmcmc_params=params), "legacy", params,
+              extra=dict(noise=0.0, noise_seed=77))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert", "dota"]
+    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert", "dota", "host", "tapes256"]
     if "pert" in what:
         make_perturbation_golden()
     if "tapes" in what:
@@ -445,3 +611,7 @@ if __name__ == "__main__":
         make_delta_cases()
     if "unet" in what:
         make_unet_golden()
+    if "host" in what:
+        make_host_golden()
+    if "tapes256" in what:
+        make_tapes_256()

@@ -8,7 +8,9 @@ from mpp_cnn_rs_object_detection_amd import energies as E
 from mpp_cnn_rs_object_detection_amd import hip_api, mappings, synth
 
 pytestmark = pytest.mark.gpu
-TAPES = ["tape_hrc_64.npz", "tape_log_96.npz", "tape_hrc_128_gt.npz", "tape_log_64_empty.npz"]
+TAPES = ["tape_hrc_64.npz", "tape_log_96.npz", "tape_hrc_128_gt.npz", "tape_log_64_empty.npz",
+         # BASELINE config 1: the 256x256 / 50-object tile, 1 000 iterations of the reference sampler (both shipped configs)
+         "tape_hrc_256.npz", "tape_log_256.npz", "tape_hrc_256_warm.npz"]
 DE_ATOL, DE_RTOL, P_RTOL = 2e-6, 2e-6, 2e-5      # vs the reference (float32 arithmetic inside numpy)
 ORC_ATOL = 1e-9                                   # vs the float64 oracle
 

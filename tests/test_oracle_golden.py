@@ -8,7 +8,8 @@ from mpp_cnn_rs_object_detection_amd import energies as E
 from mpp_cnn_rs_object_detection_amd import synth
 
 TAPES = ["tape_hrc_64.npz", "tape_log_96.npz", "tape_hrc_128_gt.npz", "tape_log_64_empty.npz",
-         "tape_hrc_96_sm.npz", "tape_log_64_sm.npz"]      # *_sm: recorded with use_split_merge=True
+         "tape_hrc_96_sm.npz", "tape_log_64_sm.npz",      # *_sm: recorded with use_split_merge=True
+         "tape_hrc_256.npz", "tape_log_256.npz", "tape_hrc_256_warm.npz"]     # BASELINE config 1 (256x256 tile)
 # energies are float64 sums of float32 map reads; the reference does part of the arithmetic in float32
 DE_ATOL, DE_RTOL, P_RTOL = 2e-6, 2e-6, 2e-5
 TIE = 1e-5   # |log u - log alpha| below which an accept decision may legitimately differ
