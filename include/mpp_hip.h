@@ -122,8 +122,11 @@ int mpp_set_stream(mpp_ctx *ctx, void *hip_stream);
 int mpp_synchronize(mpp_ctx *ctx);
 /* "spec_waves": proposals evaluated speculatively per round, one wave each (1 = strictly one at a
  * time); "spec_lanes" (0 = off): lane mode, 4 waves of which `v` lanes each evaluate one step on
- * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile, "cell_capacity" (points per
- * 32-px cell), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
+ * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per
+ * 32-px cell, at most 64), "auto_grow" (default 1): a chain that would exceed either capacity stops BEFORE that step and
+ * mpp_run / mpp_replay double the capacity (while the chain still fits the 160 KB of LDS) and continue it -- the reference's
+ * point set has no capacity (point_set/point_set.py:45-188); with 0 the call fails with -11 / -12 and the chain can be
+ * continued by hand from the written-back state ("grow_events", read-only, counts the re-launches), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
  * tile t % n_tiles; "force_accept": apply every proposal without the Metropolis test (the kernel random
  * walks of models/mpp/perturbation_sampler.py:152-169); "scratch_grid_min_points" (default 256; 0 = never): configurations of
  * at least that many points get a candidate grid (PointsSet.get_potential_neighbors, point_set.py:111-145) for

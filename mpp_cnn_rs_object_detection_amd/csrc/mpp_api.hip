@@ -11,9 +11,10 @@
 
 extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves);
 extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int occ, int grid, size_t lds,
-                                       const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
-                                       unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
+                                       const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
+                                       long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
+extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                          int n_cases, const int32_t *rem_off, const int32_t *rem,
                                          const int32_t *add_off, const int32_t *add_xy, const double *add_marks,
@@ -69,6 +70,8 @@ struct mpp_ctx {
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
   int64_t *step = nullptr;
+  long long *until = nullptr;        // per tile: the absolute step the current mpp_run / mpp_replay call runs it to
+  int auto_grow = 1, grow_events = 0; // capacity overflow -> raise the capacity and continue (see run_chain)
   std::vector<double> intensity;
   std::vector<TileRef> h_tiles;
   TileRef *d_tiles = nullptr;
@@ -123,8 +126,8 @@ static int scratch_grid(mpp_ctx *c, int tile, int n, const int32_t **start, cons
 
 static const char *chain_error_text(int e) {
   switch (e) {
-    case 1: return "a 32-px cell of the spatial hash overflowed (raise option cell_capacity)";
-    case 2: return "point capacity of the tile exceeded (raise option point_capacity)";
+    case 1: return "a cell of the spatial hash holds more points than cell_capacity (at most 64) allows";
+    case 2: return "point capacity of the tile exceeded (a larger point_capacity does not fit the chain's LDS budget, or auto_grow is off)";
     case 3: return "proposal refers to a point that does not exist or lies outside the tile";
     case 4: return "candidate list overflow (lower cell_capacity or report)";
   }
@@ -167,10 +170,10 @@ static void free_tiles(mpp_ctx *c) {
   c->det = nullptr; c->m[0] = c->m[1] = c->m[2] = nullptr;
   if (c->boxsum) { (void)hipFree(c->boxsum); c->boxsum = nullptr; }
   void *ptrs[] = {c->rowpart, c->rowbase, c->rowtot, c->px, c->py, c->n, c->errd, c->ps, c->pr, c->pa, c->T, c->step,
-                  c->d_tiles};
+                  c->d_tiles, c->until};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   c->rowpart = c->rowbase = c->rowtot = nullptr; c->px = c->py = c->n = c->errd = nullptr;
-  c->ps = c->pr = c->pa = c->T = nullptr; c->step = nullptr; c->d_tiles = nullptr;
+  c->ps = c->pr = c->pa = c->T = nullptr; c->step = nullptr; c->d_tiles = nullptr; c->until = nullptr;
 }
 
 extern "C" int mpp_destroy(mpp_ctx *c) {
@@ -226,8 +229,10 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     if (v < 0) return fail(c, -1, "scratch_grid_min_points must be >= 0");
     c->grid_min_points = (int)v;
   } else if (!strcmp(name, "cell_capacity")) {
-    if (v < 1 || v > 32) return fail(c, -1, "cell_capacity must be in 1..32");
+    if (v < 1 || v > 64) return fail(c, -1, "cell_capacity must be in 1..64");
     c->cell_cap = (int)v; c->params_dirty = true;
+  } else if (!strcmp(name, "auto_grow")) {
+    c->auto_grow = v ? 1 : 0;
   } else if (!strcmp(name, "force_accept")) {
     c->hp.force_accept = v ? 1 : 0; c->params_dirty = true;
   } else return fail(c, -1, "unknown option %s", name);
@@ -241,6 +246,8 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "replicas")) return c->replicas;
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
+  if (!strcmp(name, "auto_grow")) return c->auto_grow;
+  if (!strcmp(name, "grow_events")) return c->grow_events;
   if (!strcmp(name, "scratch_grid_min_points")) return c->grid_min_points;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
   if (!strcmp(name, "grid_nx")) return c->hp.nx;       // spatial hash dimensions (point_set.py:58-61)
@@ -366,7 +373,7 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   HIPCHK(c, dalloc(&c->px, T * c->cap)); HIPCHK(c, dalloc(&c->py, T * c->cap));
   HIPCHK(c, dalloc(&c->ps, T * c->cap)); HIPCHK(c, dalloc(&c->pr, T * c->cap)); HIPCHK(c, dalloc(&c->pa, T * c->cap));
   HIPCHK(c, dalloc(&c->n, T)); HIPCHK(c, dalloc(&c->errd, T)); HIPCHK(c, dalloc(&c->T, T * 3));
-  HIPCHK(c, dalloc(&c->step, T)); HIPCHK(c, dalloc(&c->d_tiles, T));
+  HIPCHK(c, dalloc(&c->step, T)); HIPCHK(c, dalloc(&c->d_tiles, T)); HIPCHK(c, dalloc(&c->until, T));
   HIPCHK(c, hipMemsetAsync(c->n, 0, T * sizeof(int32_t), c->stream));
   HIPCHK(c, hipMemsetAsync(c->errd, 0, T * sizeof(int32_t), c->stream));
   HIPCHK(c, hipMemsetAsync(c->step, 0, T * sizeof(int64_t), c->stream));
@@ -696,39 +703,105 @@ extern "C" int mpp_set_schedule(mpp_ctx *c, double T0, double alpha, double T_ta
   return 0;
 }
 
+// More slots per tile: the five configuration arrays are re-allocated with the new stride and copied.
+static int grow_points(mpp_ctx *c, int new_cap) {
+  const size_t T = (size_t)c->n_tiles;
+  int32_t *px = nullptr, *py = nullptr;
+  double *ps = nullptr, *pr = nullptr, *pa = nullptr;
+  HIPCHK(c, dalloc(&px, T * new_cap)); HIPCHK(c, dalloc(&py, T * new_cap));
+  HIPCHK(c, dalloc(&ps, T * new_cap)); HIPCHK(c, dalloc(&pr, T * new_cap)); HIPCHK(c, dalloc(&pa, T * new_cap));
+  const size_t wi = (size_t)c->cap * sizeof(int32_t), wd = (size_t)c->cap * sizeof(double);
+  const size_t ni = (size_t)new_cap * sizeof(int32_t), nd = (size_t)new_cap * sizeof(double);
+  HIPCHK(c, hipMemcpy2DAsync(px, ni, c->px, wi, wi, T, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(py, ni, c->py, wi, wi, T, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(ps, nd, c->ps, wd, wd, T, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(pr, nd, c->pr, wd, wd, T, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(pa, nd, c->pa, wd, wd, T, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(c->px); (void)hipFree(c->py); (void)hipFree(c->ps); (void)hipFree(c->pr); (void)hipFree(c->pa);
+  c->px = px; c->py = py; c->ps = ps; c->pr = pr; c->pa = pa;
+  c->cap = new_cap; c->g_cap = 0;
+  c->tiles_dirty = true; c->params_dirty = true;
+  return 0;
+}
+
+static size_t chain_lds(mpp_ctx *c, int cap, int cell_cap) {
+  const int ncell = c->hp.nx * c->hp.ny;
+  const int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
+  const int rb = c->hp.rowbase_lds ? c->H + 1 : 0;
+  return mpp_chain_lds_bytes(cap, ncell, cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
+}
+
+// The reference's point set has no capacity (Python sets, point_set.py:45-188); a chain here lives in one workgroup's
+// LDS with `point_capacity` slots and `cell_capacity` entries per cell of the spatial hash.  A step that would exceed
+// either stops the chain BEFORE the step (state, temperature and step counter of that moment are written back);
+// with auto_grow (default) the capacity is doubled -- as long as the chain still fits the 160 KB of LDS -- and the same
+// launch is issued again: finished tiles return at once, the stopped ones continue with the very next step, so the
+// chain is the one an unlimited capacity would have produced.
 static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t seed, uint32_t chain0,
                      const mpp_proposal *d_tape, int trace_tile, mpp_step_out *d_out, mpp_proposal *d_props) {
   if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   int rc = push_state(c);
   if (rc) return rc;
-  if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
-  const int ncell = c->hp.nx * c->hp.ny;
-  const int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
   // the row level of the birth CDF goes to LDS when it fits and the chain speculates (it shortens the slowest
   // wave of a round); throughput launches of one-wave chains keep their LDS for occupancy
   c->hp.rowbase_lds = (c->H <= 1024 && (c->lanes > 0 || c->spec > 1)) ? 1 : 0;
-  const int rb = c->hp.rowbase_lds ? c->H + 1 : 0;
-  size_t lds = mpp_chain_lds_bytes(c->cap, ncell, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
-  if (lds > MPP_LDS_LIMIT)
-    return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
-                lds, MPP_LDS_LIMIT);
-  HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-  // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
-  const int occ = (grid >= 1024) ? 2 : 1;
   if (c->hp.n_kernels > MPP_K_SPLIT && !(c->lanes == 0 && (c->spec == 1 || c->spec == 8)))
     return fail(c, -1, "the split / merge kernels are built for spec_waves 1 or 8 with spec_lanes 0");
-  HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, (long long)n_steps, seed, chain0,
-                             d_tape, trace_tile, d_out, d_props));
-  HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-  HIPCHK(c, hipEventSynchronize(c->ev1));
-  float ms = 0.f;
-  HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-  c->last_ms = ms;
-  std::vector<int32_t> herr(grid);
-  HIPCHK(c, hipMemcpy(herr.data(), c->errd + tile0, grid * sizeof(int32_t), hipMemcpyDeviceToHost));
-  for (int t = 0; t < grid; ++t)
-    if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
-  return 0;
+  mpp_launch_set_until(c->stream, c->d_tiles, tile0, grid, (long long)n_steps, c->until);
+  HIPCHK(c, hipGetLastError());
+  long long trace_base = 0;
+  if (trace_tile >= 0) {
+    int64_t s0 = 0;
+    HIPCHK(c, hipMemcpyAsync(&s0, c->step + trace_tile, sizeof s0, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    trace_base = s0;
+  }
+  c->last_ms = 0.0;
+  // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
+  const int occ = (grid >= 1024) ? 2 : 1;
+  for (;;) {
+    size_t lds = chain_lds(c, c->cap, c->cell_cap);
+    if (lds > MPP_LDS_LIMIT)
+      return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
+                  lds, MPP_LDS_LIMIT);
+    c->hp.cap = c->cap; c->hp.cell_cap = c->cell_cap;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed,
+                               chain0, d_tape, trace_tile, d_out, d_props));
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_ms += ms;
+    std::vector<int32_t> herr(grid);
+    HIPCHK(c, hipMemcpy(herr.data(), c->errd + tile0, grid * sizeof(int32_t), hipMemcpyDeviceToHost));
+    bool cell = false, point = false;
+    for (int t = 0; t < grid; ++t) {
+      if (herr[t] == 1) cell = true;
+      else if (herr[t] == 2) point = true;
+      else if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
+    }
+    if (!cell && !point) return 0;
+    // split / merge steps change two points on the live state: they are not restartable, the limits stay hard there
+    const bool can_grow = c->auto_grow && c->hp.n_kernels <= MPP_K_SPLIT;
+    int new_cell = c->cell_cap, new_cap = c->cap;
+    if (cell) new_cell = c->cell_cap * 2 > 64 ? 64 : c->cell_cap * 2;
+    if (point) new_cap = c->cap * 2 > 65535 ? 65535 : c->cap * 2;
+    if (!can_grow || (cell && new_cell == c->cell_cap) || (point && new_cap == c->cap) ||
+        chain_lds(c, new_cap, new_cell) > MPP_LDS_LIMIT) {
+      for (int t = 0; t < grid; ++t)
+        if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
+    }
+    if (point && (rc = grow_points(c, new_cap))) return rc;
+    c->cell_cap = new_cell;
+    c->grow_events += 1;
+    // clear the two overflow codes (sticky otherwise) and bring the tile table / parameters up to date
+    for (int t = 0; t < grid; ++t) if (herr[t] == 1 || herr[t] == 2) herr[t] = 0;
+    HIPCHK(c, hipMemcpy(c->errd + tile0, herr.data(), grid * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->params_dirty = true;
+    if ((rc = push_state(c))) return rc;
+  }
 }
 
 extern "C" int mpp_replay(mpp_ctx *c, int tile, int n, const mpp_proposal *tape, mpp_step_out *out) {

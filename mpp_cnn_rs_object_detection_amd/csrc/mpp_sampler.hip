@@ -12,7 +12,8 @@
 // SM: the instantiation that also knows the split / merge kernels (mpp_split_merge.hpp); the others carry none of it.
 template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
 __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
-                                                                  long long n_steps, unsigned long long seed,
+                                                                  const long long *until, long long trace_base,
+                                                                  unsigned long long seed,
                                                                   unsigned int chain0, const mpp_proposal *tape,
                                                                   int trace_tile, mpp_step_out *out,
                                                                   mpp_proposal *props) {
@@ -90,6 +91,11 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   // ---------------------------------------------------------------- the chain
   const double alpha = c.t.T[1], T_target = c.t.T[2];
   long long step0 = *c.t.step, done = 0;
+  // the launch runs every tile up to ITS absolute step until[tile]; a launch that follows a capacity overflow (the
+  // host raised the capacity and re-launched) finds the finished tiles at their end and the stopped one where it stopped
+  const long long n_steps = until[tile] - step0;
+  // records of a traced tile / tape entries are indexed from the step the host's call started at
+  const long long tr0 = step0 - trace_base;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #ifdef MPP_PROFILE
   unsigned long long prof_[16] = {0};
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       r.valid = 1;
       int keep = 0;
       if (tape) {
-        const mpp_proposal &tp = tape[my];
+        const mpp_proposal &tp = tape[tr0 + my];
         r.kernel = tp.kernel; r.tidx = tp.target; r.tslot = -1;
         r.ax = tp.ax; r.ay = tp.ay; r.as = tp.as; r.ar = tp.ar; r.aa = tp.aa; r.aux0 = tp.aux0; r.aux1 = tp.aux1;
         r.pid = tp.param_id; r.ncls = tp.new_class; r.u_acc = tp.u_accept; r.rx = r.ry = 0;
@@ -241,9 +247,14 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           const int q_pad = __builtin_amdgcn_readlane(m_pad, w);
           if (SM && q_pad != 0) { cur_n += q_pad; committed = w + 1; break; }    // a split / merge applied by sm_step()
           const int q_hr = __builtin_amdgcn_readlane(m_hr, w), q_ha = __builtin_amdgcn_readlane(m_ha, w);
+          // capacity checks BEFORE anything of step w is applied: the chain stops in the state before the step, so a
+          // re-launch with a larger capacity continues it as if there had been no limit.  (Cell counts are those of
+          // the round's start: an earlier commit of this round that touched the same cell has invalidated record w.)
+          const int q_ca_w = __builtin_amdgcn_readlane(m_ca, w), q_cr_w = __builtin_amdgcn_readlane(m_cr, w);
+          if (q_ha && q_ca_w != q_cr_w && (int)L.cell_cnt[q_ca_w] >= P->cell_cap) { err = ERR_CELL_OVERFLOW; committed = w; break; }
           if (!(q_hr && q_ha)) {                                                 // death / birth: ends the round
             if (q_hr) { commit_mask |= 1u << w; cur_n -= 1; }
-            else if (cur_n >= cap) err = ERR_POINT_OVERFLOW;
+            else if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; committed = w; break; }
             else { commit_mask |= 1u << w; cur_n += 1; }
             committed = w + 1;
             break;
@@ -311,6 +322,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       // after it (population or index->slot map changed, or an error)
       auto commit_one = [&](const Rec &q, int w) -> bool {
         if (SM && q._pad != 0) { cur_n += q._pad; return true; }      // a split / merge applied by sm_step()
+        if (q.has_add) {                                   // capacity checks before anything is applied (see above)
+          int ci, cj;
+          const int c1 = cell_index(P, q.ax, q.ay, &ci, &cj), c0 = q.has_rem ? cell_index(P, q.rx, q.ry, &ci, &cj) : -1;
+          if (c1 != c0 && (int)L.cell_cnt[c1] >= P->cell_cap) { err = ERR_CELL_OVERFLOW; return true; }
+          if (!q.has_rem && cur_n >= cap) { err = ERR_POINT_OVERFLOW; return true; }
+        }
         if (!apply_round && c.lane < q.n_stash) {
           int u = L.stash_slot[w * STASH + c.lane];
           L.red0[u] = L.stash_v0[w * STASH + c.lane];
@@ -403,6 +420,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           }
           const bool stop = commit_one(q, w);
           cur = w + 1;
+          if (err == ERR_CELL_OVERFLOW || err == ERR_POINT_OVERFLOW) { committed = w; break; }    // step w not done
           if (stop || err) { committed = w + 1; break; }
         }
         for (int i = 0; i < committed; ++i) if (Tc > T_target) Tc *= alpha;      // rjmcmc.py:158-159
@@ -425,9 +443,10 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
             break;
           }
           stop = commit_one(q, w);
+          if (err == ERR_CELL_OVERFLOW || err == ERR_POINT_OVERFLOW) break;                      // step w not done
         }
         if (tracing && c.lane == 0) {
-          long long idx = done + w;
+          long long idx = tr0 + done + w;
           if (out) {
             mpp_step_out so;
             so.dE = q.dE; so.fwd = q.fwd; so.bwd = q.bwd; so.log_alpha = q.log_alpha; so.T = Tc;
@@ -497,6 +516,16 @@ extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof2(unsi
 }
 #endif
 
+// until[t] = step[t] + n_steps for the tiles of a launch (set once per host call; re-launches after a capacity overflow
+// keep it)
+__global__ void k_set_until(const TileRef *tiles, int tile0, int n, long long n_steps, long long *until) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) until[tile0 + i] = *tiles[tile0 + i].step + n_steps;
+}
+extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until) {
+  hipLaunchKernelGGL(k_set_until, dim3((n + 255) / 256), dim3(256), 0, st, tiles, tile0, n, n_steps, until);
+}
+
 // ---- host-side launcher ----------------------------------------------------------------------------
 extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves) {
   return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n, waves);
@@ -504,43 +533,43 @@ extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec
 
 template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
 static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
-                              long long n_steps, unsigned long long seed, unsigned int chain0,
+                              const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
   hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
-                     n_steps, seed, chain0, tape, trace_tile, out, props);
+                     until, trace_base, seed, chain0, tape, trace_tile, out, props);
   return hipGetLastError();
 }
 template <int WAVES, int LPW>
 static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
-                              long long n_steps, unsigned long long seed, unsigned int chain0,
+                              const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props,
                               int occ) {
   constexpr int BASE = (WAVES + 3) / 4;      // waves per SIMD one workgroup needs anyway
   const bool diag = tape || out || props;
   if (P->n_kernels > MPP_K_SPLIT) {          // split / merge kernels in the mixture: built for 1 and 8 waves
     if constexpr (LPW == 0 && (WAVES == 1 || WAVES == 8)) {
-      if (diag) return launch_spec_d<WAVES, LPW, true, BASE, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
-      return launch_spec_d<WAVES, LPW, false, BASE, true>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+      if (diag) return launch_spec_d<WAVES, LPW, true, BASE, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
+      return launch_spec_d<WAVES, LPW, false, BASE, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
     } else {
       return hipErrorNotSupported;
     }
   }
   if (diag)
-    return launch_spec_d<WAVES, LPW, true, BASE, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+    return launch_spec_d<WAVES, LPW, true, BASE, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
   if (WAVES <= 4 && LPW == 0 && occ >= 2)
-    return launch_spec_d<WAVES, LPW, false, 2, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
-  return launch_spec_d<WAVES, LPW, false, BASE, false>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props);
+    return launch_spec_d<WAVES, LPW, false, 2, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
+  return launch_spec_d<WAVES, LPW, false, BASE, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
 }
 
 // spec = steps evaluated per round; lanes = 0: one wave per step (spec waves); lanes > 0: 4 waves x lanes lanes
 extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int occ, int grid, size_t lds,
-                                       const DevParams *P, const TileRef *tiles, int tile0, long long n_steps,
-                                       unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
+                                       const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
+                                       long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props) {
-#define GO(W, L) return launch_spec<W, L>(st, grid, lds, P, tiles, tile0, n_steps, seed, chain0, tape, trace_tile, out, props, occ)
+#define GO(W, L) return launch_spec<W, L>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props, occ)
   if (lanes == 0) {
     switch (spec) { case 1: GO(1, 0); case 2: GO(2, 0); case 4: GO(4, 0); case 8: GO(8, 0); case 16: GO(16, 0); }
   } else {
