@@ -406,11 +406,12 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
 #endif
 // `apply`: write the changed reductions straight into the caches instead of the stash (used for the rare
 // step whose neighbour updates do not fit the stash; see the kernel's "apply round").
+template <bool FAST = false>
 __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, const Rect &ar, const Geo2 &ag, double lin_a,
                              int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
-  const int np = c.np;
+  const int np = FAST ? 2 : c.np;
   const bool has_rem = rem >= 0;
   DPROF_T0();
   Geo2 gr;
@@ -477,90 +478,132 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
       if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
     }
+    DPROF(2);
     // ---- overlap terms first, in uniform control flow: every (candidate, removed/added) pair whose circumscribed
     // circles meet is clipped by the whole wave, one pair after the other (there are ~0.2 of them per step)
     double ovl_r0 = 0.0, ovl_a0 = 0.0, ovl_r1 = 0.0, ovl_a1 = 0.0;
-#pragma clang loop unroll(disable)
-    for (int p = 0; p < np; ++p) {
-      const PairRegs pto = pair_regs(c, p);
-      if (pto.kind != MPP_P_OVERLAP) continue;
-#pragma clang loop unroll(disable)
-      for (int which = 0; which < 2; ++which) {
-        const double ov = p == 0 ? oldv[0] : oldv[1];
-        bool need = active && (which == 0 ? (has_rem && d2r <= pto.maxd2 && ov != 0.0) : (has_add && d2a <= pto.maxd2));
-        const Geo2 gv = which == 0 ? gr : ag;
-        const Rect rv = which == 0 ? rr : ar;
-        const double B = geo_area(gv.g);
-        double mn = 0.0;
-        bool uf = false;
-        if (need) {
-          const double A = geo_area(gu.g), reach = gu.rad + gv.rad, d2 = (double)(which == 0 ? d2r : d2a);
-          mn = A < B ? A : B;
-          need = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
-          if (need) uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);
-        }
-        double val = 0.0;
-        unsigned long long m = __ballot(need);
-        while (m) {
-          const int src = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          Geo bu;
-          bu.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.y = __builtin_amdgcn_readlane(gu.g.y, src);
-          bu.hl = readlane_d(gu.g.hl, src); bu.hw = readlane_d(gu.g.hw, src);
-          bu.ca = readlane_d(gu.g.ca, src); bu.sa = readlane_d(gu.g.sa, src);
-          const bool u_first = __builtin_amdgcn_readlane((int)uf, src) != 0;
-          DCOUNT(8, 1);
-          double ux[4], uy[4], vx[4], vy[4];
-          geo_corners(bu, ux, uy); geo_corners(gv.g, vx, vy);
-          double sx[4], sy[4], cx[4], cy[4];          // subject = the smaller rectangle in the canonical order
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            sx[i] = u_first ? ux[i] : vx[i]; sy[i] = u_first ? uy[i] : vy[i];
-            cx[i] = u_first ? vx[i] : ux[i]; cy[i] = u_first ? vy[i] : uy[i];
-          }
-          const double area = clip_area_wave(c, sx, sy, cx, cy);
-          if (c.lane == src) val = area / (mn + AREA_EPS);
-        }
-        if (p == 0) { if (which == 0) ovl_r0 = val; else ovl_a0 = val; }
-        else { if (which == 0) ovl_r1 = val; else ovl_a1 = val; }
-      }
-    }
-    if (active) {
+    // The (p, which) bodies are macros, expanded with literal arguments in the FAST instantiation -- pair 0 = rectangle
+    // overlap / max, pair 1 = alignment / min, what both shipped energy setups use -- so that the kind switches, the
+    // reduction modes and the per-pair selects fold away; the generic instantiation loops over runtime p / which as
+    // before.  Same arithmetic either way.  (Macros, not lambdas: a closure over the candidate's state pinned that
+    // state in private memory -- 2.9 KB of scratch and a third of the speed.)
+#define MPP_OVERLAP_PW(p_, which_, pto_)                                                                                 \
+    do {                                                                                                                  \
+      const double ov = (p_) == 0 ? oldv[0] : oldv[1];                                                                    \
+      bool need = active && ((which_) == 0 ? (has_rem && d2r <= (pto_).maxd2 && ov != 0.0) : (has_add && d2a <= (pto_).maxd2)); \
+      const Geo2 gv = (which_) == 0 ? gr : ag;                                                                            \
+      const Rect rv = (which_) == 0 ? rr : ar;                                                                            \
+      const double B = geo_area(gv.g);                                                                                    \
+      double mn = 0.0;                                                                                                    \
+      bool uf = false;                                                                                                    \
+      if (need) {                                                                                                         \
+        const double A = geo_area(gu.g), reach = gu.rad + gv.rad, d2 = (double)((which_) == 0 ? d2r : d2a);               \
+        mn = A < B ? A : B;                                                                                               \
+        need = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);                                              \
+        if (need) uf = slot_first(L, u, gu.g, rv.x, rv.y, rv.s, rv.r, rv.a);                                              \
+      }                                                                                                                   \
+      double val = 0.0;                                                                                                   \
+      unsigned long long m = __ballot(need);                                                                              \
+      while (m) {                                                                                                         \
+        const int src = __ffsll((long long)m) - 1;                                                                        \
+        m &= m - 1;                                                                                                       \
+        Geo bu;                                                                                                           \
+        bu.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.y = __builtin_amdgcn_readlane(gu.g.y, src);                     \
+        bu.hl = readlane_d(gu.g.hl, src); bu.hw = readlane_d(gu.g.hw, src);                                               \
+        bu.ca = readlane_d(gu.g.ca, src); bu.sa = readlane_d(gu.g.sa, src);                                               \
+        const bool u_first = __builtin_amdgcn_readlane((int)uf, src) != 0;                                                \
+        DCOUNT(8, 1);                                                                                                     \
+        double ux[4], uy[4], vx[4], vy[4];                                                                                \
+        geo_corners(bu, ux, uy); geo_corners(gv.g, vx, vy);                                                               \
+        double sx[4], sy[4], cx[4], cy[4];          /* subject = the smaller rectangle in the canonical order */         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                   \
+          sx[i] = u_first ? ux[i] : vx[i]; sy[i] = u_first ? uy[i] : vy[i];                                               \
+          cx[i] = u_first ? vx[i] : ux[i]; cy[i] = u_first ? vy[i] : uy[i];                                               \
+        }                                                                                                                 \
+        const double area = clip_area_wave(c, sx, sy, cx, cy);                                                            \
+        if (c.lane == src) val = area / (mn + AREA_EPS);                                                                  \
+      }                                                                                                                   \
+      if ((p_) == 0) { if ((which_) == 0) ovl_r0 = val; else ovl_a0 = val; }                                              \
+      else { if ((which_) == 0) ovl_r1 = val; else ovl_a1 = val; }                                                        \
+    } while (0)
+    // which = 0: against the removed point (is it the one carrying u's extremum?)
+    // which = 1: against the added point (it may become u's new extremum)
+#define MPP_AGAINST(p_, which_, pt_)                                                                                     \
+    do {                                                                                                                  \
+      const bool in = (which_) == 0 ? (has_rem && d2r <= (pt_).maxd2 && ov != 0.0) : (has_add && d2a <= (pt_).maxd2);     \
+      if (in) {                                                                                                           \
+        const Geo2 gv = (which_) == 0 ? gr : ag;                                                                          \
+        const double pre = (p_) == 0 ? ((which_) == 0 ? ovl_r0 : ovl_a0) : ((which_) == 0 ? ovl_r1 : ovl_a1);             \
+        const double v = pair_value_pre((pt_), gu, gv, (which_) == 0 ? d2r : d2a, pre);                                   \
+        if ((which_) == 0) carries = (v == ov);                                                                           \
+        else {                                                                                                            \
+          if ((p_) == 0) ra[0] = reduce2((pt_).reduce, ra[0], v); else ra[1] = reduce2((pt_).reduce, ra[1], v);           \
+          v_add = v; got_add = true;                                                                                      \
+          any_a = true;                                                                                                   \
+        }                                                                                                                 \
+      }                                                                                                                   \
+    } while (0)
+    // u loses the neighbour that carried its extremum: every other neighbour is no more extreme than `ov`, so an added
+    // value at least as extreme IS the new extremum (exactly); otherwise u is re-reduced over its own 3x3 cells (in
+    // its lane)
+// (RESCAN_: the re-reduction call itself; the FAST instantiation defers it to ONE call site after both pairs -- with two
+// inlined copies the inliner gave up on rescan_lane, and a real call taking the Chain by reference pinned the chain state
+// and the 1.9 KB parameter block in private memory)
+#define MPP_PAIR_P(p_, pt_, UNROLLED, RESCAN_)                                                                           \
+    do {                                                                                                                  \
+      const double ov = (p_) == 0 ? oldv[0] : oldv[1];                                                                    \
+      double nv = ov, v_add = 0.0;                                                                                        \
+      bool carries = false, got_add = false;                                                                              \
+      if (UNROLLED) { MPP_AGAINST(p_, 0, pt_); MPP_AGAINST(p_, 1, pt_); }                                                 \
+      else {                                                                                                              \
+        _Pragma("clang loop unroll(disable)") for (int which = 0; which < 2; ++which) MPP_AGAINST(p_, which, pt_);        \
+      }                                                                                                                   \
+      if (carries) {                                                                                                      \
+        const bool dominates = got_add && ((pt_).reduce == MPP_REDUCE_MAX ? v_add >= ov : v_add <= ov);                   \
+        if (dominates) nv = v_add; else { RESCAN_; }                                                                      \
+      } else if (got_add) {                                                                                               \
+        nv = reduce2((pt_).reduce, ov, v_add);                                                                            \
+      }                                                                                                                   \
+      if ((p_) == 0) newv[0] = nv; else newv[1] = nv;                                                                     \
+    } while (0)
+    PairRegs f0 = c.pr0, f1 = c.pr1;                 // FAST: the kinds and reduction modes are compile-time facts
+    f0.kind = MPP_P_OVERLAP; f0.reduce = MPP_REDUCE_MAX; f1.kind = MPP_P_ALIGN; f1.reduce = MPP_REDUCE_MIN;
+    if constexpr (FAST) {
+      MPP_OVERLAP_PW(0, 0, f0);
+      MPP_OVERLAP_PW(0, 1, f0);
+    } else {
 #pragma clang loop unroll(disable)
       for (int p = 0; p < np; ++p) {
-        const PairRegs pt = pair_regs(c, p);
-        const double ov = p == 0 ? oldv[0] : oldv[1];
-        double nv = ov, v_add = 0.0;
-        bool carries = false, got_add = false;
-        // which = 0: against the removed point (is it the one carrying u's extremum?)
-        // which = 1: against the added point (it may become u's new extremum)
+        const PairRegs pto = pair_regs(c, p);
+        if (pto.kind != MPP_P_OVERLAP) continue;
 #pragma clang loop unroll(disable)
-        for (int which = 0; which < 2; ++which) {
-          const bool in = which == 0 ? (has_rem && d2r <= pt.maxd2 && ov != 0.0) : (has_add && d2a <= pt.maxd2);
-          if (!in) continue;
-          const Geo2 gv = which == 0 ? gr : ag;
-          const double pre = p == 0 ? (which == 0 ? ovl_r0 : ovl_a0) : (which == 0 ? ovl_r1 : ovl_a1);
-          const double v = pair_value_pre(pt, gu, gv, which == 0 ? d2r : d2a, pre);
-          if (which == 0) carries = (v == ov);
-          else {
-            double &rap = p == 0 ? ra[0] : ra[1];
-            rap = reduce2(pt.reduce, rap, v);
-            v_add = v; got_add = true;
-            any_a = true;
-          }
-        }
-        if (carries) {
-          // u loses the neighbour that carried its extremum.  Every other neighbour is no more extreme than `ov`,
-          // so an added value at least as extreme IS the new extremum (exactly); otherwise u is re-reduced over
-          // its own 3x3 cells (in its lane)
-          const bool dominates = got_add && (pt.reduce == MPP_REDUCE_MAX ? v_add >= ov : v_add <= ov);
-          nv = dominates ? v_add : rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
-        } else if (got_add) {
-          nv = reduce2(pt.reduce, ov, v_add);
-        }
-        if (p == 0) newv[0] = nv; else newv[1] = nv;
+        for (int which = 0; which < 2; ++which) MPP_OVERLAP_PW(p, which, pto);
       }
     }
+    DPROF(3);
+    if (active) {
+      if constexpr (FAST) {
+        bool resc0 = false, resc1 = false;
+        MPP_PAIR_P(0, f0, true, resc0 = true);
+        MPP_PAIR_P(1, f1, true, resc1 = true);
+#pragma clang loop unroll(disable)
+        for (int p = 0; p < 2; ++p)
+          if (p == 0 ? resc0 : resc1) {
+            const double v = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
+            if (p == 0) newv[0] = v; else newv[1] = v;
+          }
+      } else {
+#pragma clang loop unroll(disable)
+        for (int p = 0; p < np; ++p) {
+          const PairRegs pt = pair_regs(c, p);
+          MPP_PAIR_P(p, pt, false, nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag));
+        }
+      }
+    }
+#undef MPP_OVERLAP_PW
+#undef MPP_AGAINST
+#undef MPP_PAIR_P
+    DPROF(5);
     const bool changed = active && ((newv[0] != oldv[0]) || (newv[1] != oldv[1]));
     if (changed) {
       double lin = L.lin[u];
@@ -580,6 +623,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       }
     }
     stash_n += __popcll(cm);
+    DPROF(6);
   }
   DPROF(1);
   // combine the few lanes that contribute, in ascending lane order (deterministic, wave-uniform result)
@@ -1067,17 +1111,22 @@ __device__ void write_slot(const Chain &c, int slot, const Rec &q) {
 // dE, and the accept decision for population n at temperature T
 #ifdef MPP_PROFILE
 #define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
-template <bool LANE>
+template <bool LANE, bool FAST = false>
 __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
                          unsigned long long *prof) {
   unsigned long long pt_ = clock64();
 #else
 #define EPROF(i)
-template <bool LANE>
+template <bool LANE, bool FAST = false>
 __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply) {
 #endif
   const DevParams *P = c.P;
   const Lds &L = c.L;
+  // the score-map values of the proposed rectangle: requested first, used after the densities and the trigonometry
+  MapVals mv{0.f, 0.f, 0.f, 0.f};
+#ifndef MPP_NO_HOIST
+  if (r.has_add) mv = load_map_vals(P, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
+#endif
   proposal_densities(c, r, tracing, keep, !LANE);
   EPROF(4);
   r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
@@ -1096,7 +1145,10 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
       if (keep & KEEP_TRIG) { ag.g.ca = L.ca[r.tslot]; ag.g.sa = L.sa[r.tslot]; }
       else { double al = add.a + MPP_PI / 2.0; ag.g.ca = cos(al); ag.g.sa = sin(al); }
       EPROF(5);
-      unit_part(P, c.t, L.edges, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
+#ifdef MPP_NO_HOIST
+      mv = load_map_vals(P, c.t, L.edges, add);
+#endif
+      unit_part_mv(P, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
       r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;
       EPROF(6);
     }
@@ -1104,8 +1156,8 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
       r.dE = eval_delta_lane(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
                              &r.n_stash, apply);
     else
-      r.dE = eval_delta(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
-                        &r.n_stash, apply);
+      r.dE = eval_delta<FAST>(c, ri, r.has_rem ? r.tslot : -1, r.has_add != 0, add, ag, r.lin_a, r.gate_a, &r.ra0, &r.ra1,
+                              &r.n_stash, apply);
     EPROF(7);
   }
   double fwd, bwd;

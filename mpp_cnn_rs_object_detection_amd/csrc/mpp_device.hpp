@@ -266,10 +266,11 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
 
 // the part of a point's combined energy that does not depend on its neighbours:
 // lin = lin0 + sum_units coef*g*v ; gate = [v_gate <= thr]
-__device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
-                                 const Geo &g, double *lin, int *gate, double *vec_or_null) {
+// (two entry points: with the score-map values already fetched -- the chain issues those loads as early as it knows the
+// pixel and the marks, so that their latency overlaps the proposal densities and the trigonometry -- and without)
+__device__ inline void unit_part_mv(const DevParams *P, const MapVals &mv, const Rect &q, const Geo &g, double *lin,
+                                    int *gate, double *vec_or_null) {
   const mpp_model &M = P->model;
-  const MapVals mv = load_map_vals(P, t, edges, q);
   // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
   double vg = 0.0;
   int gt = 1;
@@ -284,6 +285,11 @@ __device__ inline void unit_part(const DevParams *P, const TileRef &t, const dou
     l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
   }
   *lin = l; *gate = gt;
+}
+__device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
+                                 const Geo &g, double *lin, int *gate, double *vec_or_null) {
+  const MapVals mv = load_map_vals(P, t, edges, q);
+  unit_part_mv(P, mv, q, g, lin, gate, vec_or_null);
 }
 __device__ __forceinline__ double pair_part(const DevParams *P, int gate, double r0, double r1) {
   const mpp_model &M = P->model;

@@ -1,4 +1,6 @@
 // mpp_sampler.hip -- the chain kernels (see mpp_chain.hpp for the design notes and the shared pieces)
+#include <cstdlib>
+
 #include "mpp_chain.hpp"
 #include "mpp_split_merge.hpp"
 
@@ -10,7 +12,9 @@
 // SIMD).  Throughput runs over many one-wave chains ask for OCC = 2 explicitly so that two chains share a SIMD and
 // hide each other's latencies.
 // SM: the instantiation that also knows the split / merge kernels (mpp_split_merge.hpp); the others carry none of it.
-template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
+// FAST: the energy model is (pair 0 = rectangle overlap / max, pair 1 = alignment / min) -- both shipped setups; the pair
+// loops of eval_delta are then straight-line code (chosen by the host; the generic instantiations cover everything else).
+template <int WAVES, int LPW, bool DIAG, int OCC, bool SM, bool FAST = false>
 __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
                                                                   const long long *until, long long trace_base,
                                                                   unsigned long long seed,
@@ -185,9 +189,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         }
       } else if (r.valid) {
 #ifdef MPP_PROFILE
-        evaluate<LANE>(c, r, ri, keep, n, T, tracing, apply_round, prof_);
+        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, prof_);
 #else
-        evaluate<LANE>(c, r, ri, keep, n, T, tracing, apply_round);
+        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round);
 #endif
       }
 #ifdef MPP_PROFILE
@@ -531,14 +535,14 @@ extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec
   return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n, waves);
 }
 
-template <int WAVES, int LPW, bool DIAG, int OCC, bool SM>
+template <int WAVES, int LPW, bool DIAG, int OCC, bool SM, bool FAST = false>
 static hipError_t launch_spec_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                               const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
                               const mpp_proposal *tape, int trace_tile, mpp_step_out *out, mpp_proposal *props) {
-  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>,
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM, FAST>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
+  hipLaunchKernelGGL((mpp_chain_kernel<WAVES, LPW, DIAG, OCC, SM, FAST>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0,
                      until, trace_base, seed, chain0, tape, trace_tile, out, props);
   return hipGetLastError();
 }
@@ -559,6 +563,18 @@ static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevPar
   }
   if (diag)
     return launch_spec_d<WAVES, LPW, true, BASE, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
+  // the production launches of the shipped energy setups: pair loops specialised (FAST); MPP_NO_FAST=1 keeps the generic code
+  const mpp_model &M = P->model;
+  static const bool no_fast = getenv("MPP_NO_FAST") != nullptr;
+  const bool fast = !no_fast && M.n_pair == 2 && M.pair[0].kind == MPP_P_OVERLAP && M.pair[0].reduce == MPP_REDUCE_MAX &&
+                    M.pair[1].kind == MPP_P_ALIGN && M.pair[1].reduce == MPP_REDUCE_MIN;
+  if constexpr (LPW == 0 && WAVES <= 8) {
+    if (fast) {
+      if (WAVES <= 4 && occ >= 2)
+        return launch_spec_d<WAVES, LPW, false, 2, false, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
+      return launch_spec_d<WAVES, LPW, false, BASE, false, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
+    }
+  }
   if (WAVES <= 4 && LPW == 0 && occ >= 2)
     return launch_spec_d<WAVES, LPW, false, 2, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
   return launch_spec_d<WAVES, LPW, false, BASE, false>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);

@@ -8,7 +8,7 @@ import bench
 from mpp_cnn_rs_object_detection_amd import kernels, mappings, synth
 setup, model = bench.load_model(); maps = mappings.default_mappings()
 t = synth.make_tile(512, 200, 0)
-for spec, lanes in ((1, 0), (8, 0), (1, 1), (1, 4)):
+for spec, lanes in ((1, 0), (8, 0)):
     ctx = hip_api.MppContext(0, point_capacity=1024, spec_waves=spec, spec_lanes=lanes)
     ctx.set_maps(t.det, t.marks); ctx.set_model(model, maps); ctx.naive_init(setup.detection_threshold, 6.0)
     xy, mk = ctx.get_points(); ctx.set_kernels(kernels.make_kernels(maps, float(len(xy))))
@@ -17,7 +17,7 @@ for spec, lanes in ((1, 0), (8, 0), (1, 1), (1, 4)):
     buf = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof(buf)
     v = np.array(list(buf), dtype=float); names = ['draw','evaluate','commit','sync','dens','geom','unit','evalD','green','barrier_wait']
     buf2 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof2(buf2, 1)
-    print('   evalD parts (setup, cand, slow, stash, combine):', [round(x/100001) for x in list(buf2)[:5]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001, 'zero-area clips/step', buf2[12]/100001)
+    print('   evalD parts (setup, after-pass, cand-loads, overlap-phase, combine, pair-loop, finish+stash):', [round(x/100001) for x in list(buf2)[:7]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001, 'zero-area clips/step', buf2[12]/100001)
     buf3 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof3(buf3)
     buf4 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof4(buf4)
     print('   draw cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf4[k]/max(1,buf3[8+k])) for k in range(8)])

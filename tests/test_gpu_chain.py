@@ -165,6 +165,7 @@ def test_many_tiles_in_one_launch_are_independent_chains():
 
 def test_capacity_overflow_is_reported():
     t, o, ctx = setup_case(64, 8, "legacy", cap=9)
+    ctx.set_option("auto_grow", 0)           # (with auto_grow the capacity is raised instead: tests/test_gpu_capacity.py)
     ctx.set_schedule(1e6, 1.0, 0.0)          # everything is accepted: births pile up
     with pytest.raises(hip_api.MppError):
         ctx.run(5000, 1)
