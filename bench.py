@@ -23,6 +23,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# The roof the chain kernel actually sits under (profiles/r02b_lanes.md): issue of (mostly float64) vector instructions.
+# One SIMD issues one wave64 vector instruction per 4 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"):
+N_SIMD, CLOCK_GHZ = 1024, 2.4
+VALU_PEAK_GINSTR = N_SIMD * CLOCK_GHZ / 4.0        # 614.4 G wave-instructions / s on 256 CUs
 
 
 def load_model():
@@ -151,6 +155,30 @@ def main():
     d = np.sqrt(((final_xy[:, None, :] - tiles[0].gt_xy[None]) ** 2).sum(-1)) if len(final_xy) else np.zeros((0, 1))
     matched = int((d.min(axis=0) <= 2).sum()) if len(final_xy) else 0
 
+    lanes = {}
+    lj = os.path.join(REPO, "profiles", "latest_lanes.json")
+    if os.path.exists(lj):           # committed rocprofv3 counters of the same two launches (profiles/tools/pmc_lanes.sh)
+        with open(lj) as f:
+            lanes = json.load(f)
+
+    def valu_roofline(kind, proposals_per_s, simds_in_use):
+        """float64 vector-instruction issue: achieved = measured instructions per proposal (committed PMC pass) x the
+        proposal rate measured live; peak = one wave instruction per SIMD per 4 cycles on all 1024 SIMDs"""
+        L = lanes.get(kind)
+        if not L:
+            return None
+        ach = L["valu_instructions_per_proposal"] * proposals_per_s / 1e9
+        return {"bound": "fp64-valu-issue", "achieved": ach, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instructions/s",
+                "frac": ach / VALU_PEAK_GINSTR,
+                "frac_of_the_simds_in_use": ach / (VALU_PEAK_GINSTR * simds_in_use / N_SIMD), "simds_in_use": simds_in_use,
+                "valu_instructions_per_proposal": L["valu_instructions_per_proposal"],
+                "salu_instructions_per_proposal": L["salu_instructions_per_proposal"],
+                "exec_lanes_per_valu_cycle": L["exec_lanes_per_valu_cycle"],
+                "useful_lanes_note": "EXEC is wide (45 of 64 lanes on average) because wave-uniform work -- Philox, the draw, "
+                                     "densities, the Green ratio -- runs redundantly in every lane; lanes doing DISTINCT work: "
+                                     "one per candidate neighbour (~7 of 64) in eval_delta, 4-8 in the clipper, 1 elsewhere",
+                "counters_source": lanes.get("source"), "counter_kernel": L["kernel"]}
+
     traffic, traffic_src, valu_busy = None, None, None
     tj = os.path.join(REPO, "profiles", "latest_traffic.json")
     if os.path.exists(tj):          # PMC passes cannot run inside this timed process; this is the committed rocprofv3
@@ -173,17 +201,23 @@ def main():
             "accept_rate": acc, "mean_points": mean_n, "final_points": int(len(final_xy)),
             "gt_matched_within_2px": matched, "gt_objects": int(len(tiles[0].gt_xy)),
         },
-        "roofline": {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "bytes per launch",
-            "algorithmic_bytes_per_launch": bpp * T * args.iters,
-            "kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms,
-            "algorithmic_bytes_per_proposal": bpp,
-            "note": "one chain is latency-bound on its own dependency chain; it occupies 1 of 256 CUs",
-            "occupied_cu_valu_busy_frac": valu_busy,    # SQ_ACTIVE_INST_VALU of the committed PMC pass: how busy the vector
-                                                        # ALUs of that one CU are (the roof this kernel actually sits under)
-        },
     }
+    hbm = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "bytes per launch",
+        "algorithmic_bytes_per_launch": bpp * T * args.iters, "algorithmic_bytes_per_proposal": bpp,
+    }
+    # The dominant kernel is `mpp_chain_kernel`.  Its roof is float64 vector-instruction issue, not HBM (the configuration
+    # lives in LDS; measured HBM traffic is below the algorithmic bytes): the primary block prices it against that roof,
+    # the SURVEY 8(d) HBM figure stays as `roofline.hbm`.
+    roof = valu_roofline("one", T * args.iters / (kernel_ms * 1e-3), 4 * T) if T == 1 else None
+    if roof is None:
+        roof = dict(hbm)
+    roof.update({"kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms, "traffic": traffic, "hbm": hbm,
+                 "occupied_cu_valu_busy_frac": valu_busy,
+                 "note": "one chain = one workgroup (8 speculative waves) = 1 of 256 CUs; `frac` is against the whole chip, "
+                         "`frac_of_the_simds_in_use` against the 4 SIMDs it occupies; many chains: see `batched.roofline`"})
+    result["roofline"] = roof
 
     if rank == 0 and T >= 1 and not args.no_convergence:
         # Wall-clock to convergence (BASELINE metric), untimed extra chain of tile 0 run in chunks:
@@ -238,21 +272,29 @@ def main():
         result["batched"] = {
             "tiles": B, "distinct_tiles": len(base), "point_capacity": args.batched_capacity, "tile": bt, "objects": bobj, "iters": biters, "spec_waves": args.batched_spec,
             "proposals_per_s": brate, "kernel_ms": kms, "wall_s": wall, "mean_final_points": float(n_end.mean()),
-            "roofline": {"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS},
+            "roofline": dict(valu_roofline("many", brate, N_SIMD) or {},
+                             hbm={"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS}),
             "note": "one workgroup per tile, all tiles in one launch; the reference's own parallel axis",
         }
         bctx.close()
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle                     # the CPU restatement, timed as the baseline ("port")
-        o = oracle.Oracle(tiles[0].shape, tiles[0].det, tiles[0].marks, model,
-                          kernels.make_kernels(maps, float(intensity[0])))
+        from concurrent.futures import ThreadPoolExecutor
+        kd_cpu = kernels.make_kernels(maps, float(intensity[0]))
+
+        def cpu_chains(seeds):
+            """`len(seeds)` complete chains of the bench tile on one thread (the C call releases the GIL)"""
+            o = oracle.Oracle(tiles[0].shape, tiles[0].det, tiles[0].marks, model, kd_cpu)
+            for s in seeds:
+                o.set_points(*inits[0])
+                o.set_temperature(T0, alpha, Tt)
+                o.run(args.iters, s, chain=0)
+            return len(seeds)
+
         t1 = time.perf_counter()
-        for s in range(args.cpu_baseline_chains):
-            o.set_points(*inits[0])
-            o.set_temperature(T0, alpha, Tt)
-            o.run(args.iters, s, chain=0)
+        cpu_chains(range(args.cpu_baseline_chains))
         dt = time.perf_counter() - t1
         result["cpu_baseline"] = {
             "value": args.cpu_baseline_chains * args.iters / dt, "unit": "proposals/s", "cores": 1, "kind": "port",
@@ -260,6 +302,25 @@ def main():
                       f"(oracle/mpp_oracle.c, gcc -O2, 1 thread, {os.cpu_count()} host cores present)",
             "reference_python_probe": "0.73e3 proposals/s (reference NumPy sampler, 512x512/200 objects, 1 core of "
                                       "the build container, BASELINE.md section 2; the reference cannot travel to the GPU box)",
+        }
+        # all host cores this job may use: the reference's own parallel mode is a process pool over tiles
+        # (train_utils.py:11-18); here one chain of the same tile per worker thread, each with its own oracle state
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, int(os.environ.get("MPP_CPU_CORES", "16"))))    # a 1-GPU box grants 16 cores of the host
+        per = max(1, int(round(args.cpu_baseline_chains / 3)))
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as pool:
+            done_chains = sum(pool.map(cpu_chains, [range(1000 * w, 1000 * w + per) for w in range(cores)]))
+        dt = time.perf_counter() - t1
+        result["cpu_baseline_all_cores"] = {
+            "value": done_chains * args.iters / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} threads x {per} chains x {args.iters} steps, one tile per thread (the reference's Pool-over-tiles mode, "
+                      f"train_utils.py:11-18); {avail} cores visible to the job, {os.cpu_count()} on the host",
+            "gpu_over_cpu_one_tile": value / (done_chains * args.iters / dt) if T == 1 else None,
+            "gpu_batched_over_cpu": (result.get("batched", {}).get("proposals_per_s") or 0.0) / (done_chains * args.iters / dt) or None,
         }
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 tag = sys.argv[1]
@@ -14,6 +15,7 @@ src = os.path.join("gpurun_out", f"prof_lanes_{tag}")
 GHZ = 2.4
 print(f"# lane occupancy of `mpp_chain_kernel` ({tag})\n")
 print("Source: `bash profiles/tools/pmc_lanes.sh %s` on one MI355X; one --pmc pass per launch kind, --kernel-trace only.\n" % tag)
+summary = {}
 for kind in ("one", "many"):
     rows = {}
     for p in sorted(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))):
@@ -26,7 +28,9 @@ for kind in ("one", "many"):
                 agg[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
         if not agg:
             continue
-        d = max(agg, key=lambda k: dur.get(k, (0, ""))[0])       # the longest chain launch of the run
+        # the longest PRODUCTION launch of the run (template argument DIAG = false: "<W, 0, false, ...>"), not the traced chain
+        prod = [k for k in agg if re.search(r"<\d+, \d+, false,", dur.get(k, (0, ""))[1])] or list(agg)
+        d = max(prod, key=lambda k: dur.get(k, (0, ""))[0])
         rows = dict(agg[d], ns=dur[d][0], name=dur[d][1])
     if not rows:
         print(f"## {kind}: no chain-kernel dispatch found\n")
@@ -69,3 +73,9 @@ for kind in ("one", "many"):
     if act and inst:
         print(f"| quad-cycles per VALU instruction: ACTIVE_INST_VALU / INSTS_VALU | {act / inst:.2f} |")
     print()
+    summary[kind] = {"kernel": rows["name"].split("(")[0], "kernel_ms_under_profiler": ns / 1e6, "proposals": proposals,
+                     "valu_instructions_per_proposal": inst / proposals, "salu_instructions_per_proposal": rows.get("SQ_INSTS_SALU", 0) / proposals,
+                     "valu_busy_frac_of_simds_in_use": act * 4 / n_simd / cyc if act else None, "simds_in_use": n_simd,
+                     "exec_lanes_per_valu_cycle": thr / act if act and thr else None}
+with open(os.path.join(src, "lanes.json"), "w") as f:
+    json.dump(dict(summary, source=f"profiles/tools/pmc_lanes.sh {tag} (rocprofv3 --pmc, one pass per launch kind)"), f, indent=1)
