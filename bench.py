@@ -107,11 +107,14 @@ def main():
             ctx.set_points(i, xy, mk)
         ctx.set_schedule(T0, alpha, Tt)
         ctx.run(args.iters, seed=seed, chain0=rank * T)
-        if world > 1:
-            pts = [ctx.get_points(i) for i in range(T)]
-            buf = mdist.pack_detections([rank * T + i for i in range(T)], pts, [None] * T, capacity=1024 * T)
-            mdist.all_gather_detections(buf, device=gather_device)
+        if world > 1:          # the product's exchange: records packed on the device, ONE all-gather (RCCL over xGMI)
+            ctx.pack_detections(tile_ids, anchors0, gather_cap, gather_buf)
+            mdist.all_gather_detections(gather_buf, device=gather_device)
         return ctx.last_kernel_ms()
+
+    tile_ids, anchors0 = np.arange(rank * T, rank * T + T), np.zeros((T, 2), np.int32)
+    gather_cap = mdist.gather_capacity(world * T, world)
+    gather_buf = torch.zeros((gather_cap + 1, mdist.RECORD), dtype=torch.float64, device=device) if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -129,9 +132,8 @@ def main():
     if world > 1:
         # communicator set-up (RCCL ring over xGMI) is not part of a step: one throw-away gather before anything is timed,
         # also when the driver asks for --warmup 0
-        pts0 = [ctx.get_points(i) for i in range(T)]
-        mdist.all_gather_detections(mdist.pack_detections([rank * T + i for i in range(T)], pts0, [None] * T, capacity=1024 * T),
-                                    device=gather_device)
+        ctx.pack_detections(tile_ids, anchors0, gather_cap, gather_buf)
+        mdist.all_gather_detections(gather_buf, device=gather_device)
     for w in range(args.warmup):
         one_chain(seed=w)
     barrier()
