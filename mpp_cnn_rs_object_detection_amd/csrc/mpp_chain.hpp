@@ -581,23 +581,151 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       }
     }
     DPROF(3);
-    if (active) {
-      if constexpr (FAST) {
-        bool resc0 = false, resc1 = false;
+    if constexpr (FAST) {
+      bool resc0 = false, resc1 = false;
+      if (active) {
         MPP_PAIR_P(0, f0, true, resc0 = true);
         MPP_PAIR_P(1, f1, true, resc1 = true);
-#pragma clang loop unroll(disable)
-        for (int p = 0; p < 2; ++p)
-          if (p == 0 ? resc0 : resc1) {
-            const double v = rescan_lane(c, p, u, gu, rem, has_add, ar, ag);
-            if (p == 0) newv[0] = v; else newv[1] = v;
-          }
-      } else {
-#pragma clang loop unroll(disable)
-        for (int p = 0; p < np; ++p) {
-          const PairRegs pt = pair_regs(c, p);
-          MPP_PAIR_P(p, pt, false, nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag));
+      }
+#ifdef MPP_EXP_NORESCAN      /* timing experiment only: how much do the re-reductions cost? (wrong chain) */
+      resc0 = resc1 = false;
+#endif
+      // ---- a neighbour lost the point that carried its extremum (its alignment minimum: 0.12 times per step; its
+      // overlap maximum: rarely, often in crowded scenes) and the added point does not take over: re-reduce it over its
+      // own 3x3 cells.  Done in one lane (rescan_lane, what the generic instantiation does) this walk -- nine cells,
+      // dependent LDS reads per entry, an inlined clipper -- cost ~50 VGPRs of pressure in the hottest region of the
+      // kernel (256 registers and spills instead of ~200: 12 % of the speed) and ~2 000 cycles of one straggling wave.
+      // Here the whole wave does it: the neighbour is broadcast (scalar registers), lane 3k+e takes entry e of cell k
+      // (fuller cells: a flattened index space, 64 entries per turn), overlaps that need clipping go through the
+      // wave-wide clipper one after the other, the extremum is collected with ballots and readlanes.  Same values, same
+      // (exact) max / min: the same result as the in-lane walk.
+      unsigned long long rm = __ballot(resc0 || resc1);
+      while (rm) {
+        const int src = __ffsll((long long)rm) - 1;
+        rm &= rm - 1;
+        const bool need0 = __builtin_amdgcn_readlane((int)resc0, src) != 0, need1 = __builtin_amdgcn_readlane((int)resc1, src) != 0;
+        const int us = __builtin_amdgcn_readlane(u, src);
+        Geo2 bu;                                           // the neighbour, wave-uniform
+        bu.g.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.g.y = __builtin_amdgcn_readlane(gu.g.y, src);
+        bu.g.hl = readlane_d(gu.g.hl, src); bu.g.hw = readlane_d(gu.g.hw, src);
+        bu.g.ca = readlane_d(gu.g.ca, src); bu.g.sa = readlane_d(gu.g.sa, src); bu.rad = readlane_d(gu.rad, src);
+        int uci, ucj;
+        cell_index(P, bu.g.x, bu.g.y, &uci, &ucj);
+        int cell2 = -1;
+        if (ck < 9) {
+          const int i = uci + ck / 3 - 1, j = ucj + ck % 3 - 1;
+          if (i >= 0 && i < P->nx && j >= 0 && j < P->ny) cell2 = j + i * P->ny;
         }
+        const int cnt2 = cell2 >= 0 ? (int)L.cell_cnt[cell2] : 0;
+        const bool direct2 = __ballot(cnt2 > 3) == 0ull;
+        int M2 = WAVE;
+        if (!direct2) {
+          M2 = 0;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) M2 += __builtin_amdgcn_readlane(cnt2, 3 * k);
+        }
+        const double rew = f1.p0 != 0.0 ? 1.0 : 0.0, Au = geo_area(bu.g);
+        double acc0 = 0.0, acc1 = 0.0;                     // wave-uniform results
+        for (int base2 = 0; base2 < M2; base2 += WAVE) {
+          int it_base = cell2 * P->cell_cap, it_e = ce;
+          bool act2 = ce < cnt2;
+          if (!direct2) {
+            const int j = base2 + c.lane;
+            int lo = 0, my_lo = 0;
+            it_base = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+              const int cnt_k = __builtin_amdgcn_readlane(cnt2, 3 * k), cell_k = __builtin_amdgcn_readlane(cell2, 3 * k);
+              if (j >= lo && cnt_k > 0) { my_lo = lo; it_base = cell_k * P->cell_cap; }
+              lo += cnt_k;
+            }
+            act2 = j < M2;
+            it_e = j - my_lo;
+          }
+          const int w = act2 ? (int)L.cell_items[it_base + it_e] : 0;
+          if (act2 && (w == us || w == rem)) act2 = false;
+          int wx = 0, wy = 0, d2w = 0;
+          if (act2) {
+            const int wxy = L.xy[w];
+            wx = wxy & 0xffff; wy = (wxy >> 16) & 0xffff;
+            const int dx = bu.g.x - wx, dy = bu.g.y - wy;
+            d2w = dx * dx + dy * dy;
+          }
+          if (need1) {                                     // alignment, reduced with min
+            double v1 = 0.0;
+            if (act2 && d2w <= f1.maxd2) v1 = 1.0 - fabs(bu.g.ca * L.ca[w] + bu.g.sa * L.sa[w]) - rew;
+            unsigned long long bm = __ballot(v1 < 0.0);
+            while (bm) {
+              const int l2 = __ffsll((long long)bm) - 1;
+              bm &= bm - 1;
+              acc1 = reduce2(MPP_REDUCE_MIN, acc1, readlane_d(v1, l2));
+            }
+          }
+          if (need0) {                                     // overlap, reduced with max
+            bool needc = act2 && d2w <= f0.maxd2;
+            Geo gw;
+            gw.x = wx; gw.y = wy; gw.hl = gw.hw = gw.ca = gw.sa = 0.0;
+            double mn = 0.0;
+            bool uf = false;
+            if (needc) {
+              gw.hl = L.hl[w]; gw.hw = L.hw[w]; gw.ca = L.ca[w]; gw.sa = L.sa[w];
+              const double B = geo_area(gw), reach = bu.rad + L.rad[w], d2 = (double)d2w;
+              mn = Au < B ? Au : B;
+              needc = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
+              if (needc) uf = slot_first(L, us, bu.g, wx, wy, L.s[w], L.r[w], L.a[w]);
+            }
+            unsigned long long m = __ballot(needc);
+            while (m) {
+              const int l2 = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              Geo bw;
+              bw.x = __builtin_amdgcn_readlane(gw.x, l2); bw.y = __builtin_amdgcn_readlane(gw.y, l2);
+              bw.hl = readlane_d(gw.hl, l2); bw.hw = readlane_d(gw.hw, l2);
+              bw.ca = readlane_d(gw.ca, l2); bw.sa = readlane_d(gw.sa, l2);
+              const bool u_first = __builtin_amdgcn_readlane((int)uf, l2) != 0;
+              const double mn2 = readlane_d(mn, l2);
+              double ux[4], uy[4], vx[4], vy[4];
+              geo_corners(bu.g, ux, uy); geo_corners(bw, vx, vy);
+              double sx[4], sy[4], cx[4], cy[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                sx[i] = u_first ? ux[i] : vx[i]; sy[i] = u_first ? uy[i] : vy[i];
+                cx[i] = u_first ? vx[i] : ux[i]; cy[i] = u_first ? vy[i] : uy[i];
+              }
+              acc0 = reduce2(MPP_REDUCE_MAX, acc0, clip_area_wave(c, sx, sy, cx, cy) / (mn2 + AREA_EPS));
+            }
+          }
+        }
+        if (has_add) {                                     // the proposed rectangle is a neighbour too (uniform)
+          const int dx = bu.g.x - ag.g.x, dy = bu.g.y - ag.g.y, d2a2 = dx * dx + dy * dy;
+          if (need1 && d2a2 <= f1.maxd2)
+            acc1 = reduce2(MPP_REDUCE_MIN, acc1, 1.0 - fabs(bu.g.ca * ag.g.ca + bu.g.sa * ag.g.sa) - rew);
+          if (need0 && d2a2 <= f0.maxd2) {
+            const double B = geo_area(ag.g), mn = Au < B ? Au : B, reach = bu.rad + ag.rad, d2 = (double)d2a2;
+            if (!(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001)) {
+              const bool u_first = slot_first(L, us, bu.g, ar.x, ar.y, ar.s, ar.r, ar.a);
+              double ux[4], uy[4], vx[4], vy[4];
+              geo_corners(bu.g, ux, uy); geo_corners(ag.g, vx, vy);
+              double sx[4], sy[4], cx[4], cy[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                sx[i] = u_first ? ux[i] : vx[i]; sy[i] = u_first ? uy[i] : vy[i];
+                cx[i] = u_first ? vx[i] : ux[i]; cy[i] = u_first ? vy[i] : uy[i];
+              }
+              acc0 = reduce2(MPP_REDUCE_MAX, acc0, clip_area_wave(c, sx, sy, cx, cy) / (mn + AREA_EPS));
+            }
+          }
+        }
+        if (c.lane == src) {
+          if (need0) newv[0] = acc0;
+          if (need1) newv[1] = acc1;
+        }
+      }
+    } else if (active) {
+#pragma clang loop unroll(disable)
+      for (int p = 0; p < np; ++p) {
+        const PairRegs pt = pair_regs(c, p);
+        MPP_PAIR_P(p, pt, false, nv = rescan_lane(c, p, u, gu, rem, has_add, ar, ag));
       }
     }
 #undef MPP_OVERLAP_PW
@@ -906,6 +1034,15 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     r.aa = P->maps.vmin[2] + (P->maps.vmax[2] - P->maps.vmin[2]) * u32d(w[7]);
     return;
   }
+#ifdef MPP_EXP_CHEAPDB         /* timing experiment only: a data-driven birth that costs what a uniform one does (wrong chain) */
+  if (k == MPP_K_DBIRTH) {
+    r.has_add = 1;
+    r.ax = (int)mulhi32(w[3], (uint32_t)P->H); r.ay = (int)mulhi32(w[4], (uint32_t)P->W);
+    r.as = c.L.edges[(int)mulhi32(w[5], 32u)]; r.ar = c.L.edges[MPP_NCLASS + (int)mulhi32(w[6], 32u)]; r.aa = c.L.edges[2 * MPP_NCLASS + (int)mulhi32(w[7], 32u)];
+    r.qf = 1.0; *keep = KEEP_QF;
+    return;
+  }
+#endif
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
     const double u = u53(w[3], w[4]), tot = c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H];

@@ -11,6 +11,7 @@ for f in csrc/*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -fvisibility=hidden -std=c++17 $extra "$@" -c $f -o $tmp/$(basename $f .hip).o &
 done
 wait
+for f in csrc/*.hip; do test -s $tmp/$(basename $f .hip).o || { echo "compile of $f failed"; exit 1; }; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libmppgpu_$name.so $tmp/*.o
 rm -rf $tmp
 ls -la libmppgpu_$name.so
