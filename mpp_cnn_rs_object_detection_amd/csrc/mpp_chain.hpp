@@ -39,6 +39,10 @@ __device__ unsigned long long g_prof[16];
 __device__ unsigned long long g_prof3[16];
 __device__ unsigned long long g_prof4[16];
 __device__ unsigned long long g_prof2[16];
+// straggler statistics of the rounds of 8 speculative steps: [k] rounds whose slowest wave ran kernel k, [8+k] its time,
+// [16+k] its lead over the second slowest, [24] rounds, [25] sum of max, [26] sum of mean, [27] rounds whose slowest wave
+// re-reduced a neighbour, [28+k] steps of kernel k (all waves), [36+k] their time, [44] steps with a re-reduction, [45] their time
+__device__ unsigned long long g_strag[64];
 #define PROF_T0() unsigned long long pt_ = clock64()
 #define PROF_ADD(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof_[i] += n_ - pt_; pt_ = n_; } while (0)
 #else
@@ -600,6 +604,9 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       // wave-wide clipper one after the other, the extremum is collected with ballots and readlanes.  Same values, same
       // (exact) max / min: the same result as the in-lane walk.
       unsigned long long rm = __ballot(resc0 || resc1);
+#ifdef MPP_PROFILE
+      if (rm && c.lane == 0) c.L.sh[8 + (c.wave & 7)] = 1;
+#endif
       while (rm) {
         const int src = __ffsll((long long)rm) - 1;
         rm &= rm - 1;

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
     const int n = __builtin_amdgcn_readfirstlane(L.sh[0]);
     double T = *(double *)(L.sh + 4);
     PROF_T0();
+#ifdef MPP_PROFILE
+    const unsigned long long pt_round_ = clock64();
+#endif
     // ---- phase A: record ri of this round = step done+ri, evaluated against the current state on the
     //      assumption that the steps before it in this round change nothing it depends on
     // "apply round": the previous round met an accepted step whose neighbour updates overflow the stash;
@@ -199,10 +202,42 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
 #endif
       PROF_ADD(1);
     }
+#ifdef MPP_PROFILE
+    if (SPEC == 8 && !LANE) {            // this wave's time for its step of the round, and whether it re-reduced a neighbour
+      r.fwd = (double)(clock64() - pt_round_); r.bwd = (double)L.sh[8 + (c.wave & 7)];
+      if (c.lane == 0) L.sh[8 + (c.wave & 7)] = 0;
+    }
+#endif
     if (SPEC > 1) {
       if (LANE ? (c.lane < LPW) : (c.lane == 0)) L.rec[ri] = r;    // also the idle ones of an apply round (valid = 0)
       __syncthreads();
     }
+#ifdef MPP_PROFILE
+    if (SPEC == 8 && !LANE && c.wave == 0 && !tracing) {
+      const Rec &pr_ = L.rec[c.lane < 8 ? c.lane : 0];
+      const double t_ = c.lane < 8 && pr_.valid ? pr_.fwd : 0.0;
+      const int k_ = pr_.kernel, rs_ = (int)pr_.bwd;
+      double mx = 0.0, second = 0.0, sum = 0.0; int arg = 0, nv_ = 0;
+      for (int i = 0; i < 8; ++i) {
+        const double ti = readlane_d(t_, i);
+        if (ti > 0) { sum += ti; ++nv_; }
+        if (ti > mx) { second = mx; mx = ti; arg = i; } else if (ti > second) second = ti;
+      }
+      if (nv_ == 8) {
+        const int ka = __builtin_amdgcn_readlane(k_, arg), ra = __builtin_amdgcn_readlane(rs_, arg);
+        if (c.lane == 0 && ka >= 0 && ka < 8) {
+          atomicAdd(&g_strag[ka], 1ull); atomicAdd(&g_strag[8 + ka], (unsigned long long)mx);
+          atomicAdd(&g_strag[16 + ka], (unsigned long long)(mx - second));
+          atomicAdd(&g_strag[24], 1ull); atomicAdd(&g_strag[25], (unsigned long long)mx); atomicAdd(&g_strag[26], (unsigned long long)(sum / 8));
+          if (ra) atomicAdd(&g_strag[27], 1ull);
+        }
+        if (c.lane < 8 && k_ >= 0 && k_ < 8) {
+          atomicAdd(&g_strag[28 + k_], 1ull); atomicAdd(&g_strag[36 + k_], (unsigned long long)t_);
+          if (rs_) { atomicAdd(&g_strag[44], 1ull); atomicAdd(&g_strag[45], (unsigned long long)t_); }
+        }
+      }
+    }
+#endif
     PROF_ADD(9);
     // ---- phase B, untraced wave mode: wave 0 DECIDES in order which records commit (registers, ballots and readlanes
     //      only), then every chosen record is applied by the wave that evaluated it, all at once.  Two records of one
@@ -503,6 +538,10 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
 #ifdef MPP_PROFILE
 extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 16);
+}
+extern "C" __attribute__((visibility("default"))) void mpp_debug_read_strag(unsigned long long *out) {
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_strag), sizeof(unsigned long long) * 64);
+  unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_strag), z, sizeof z);
 }
 extern "C" __attribute__((visibility("default"))) void mpp_debug_read_prof4(unsigned long long *out) {
   (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof4), sizeof(unsigned long long) * 16);

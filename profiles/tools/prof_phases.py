@@ -22,4 +22,9 @@ for spec, lanes in ((1, 0), (8, 0)):
     buf4 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof4(buf4)
     print('   draw cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf4[k]/max(1,buf3[8+k])) for k in range(8)])
     print('   evaluate cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf3[k]/max(1,buf3[8+k])) for k in range(8)], 'counts', list(buf3)[8:16])
+    if spec == 8:
+        sb = (ctypes.c_ulonglong * 64)(); L.mpp_debug_read_strag(sb); g = list(sb); R = max(1, g[24])
+        print('   rounds', g[24], 'mean of round max', round(g[25] / R), 'mean of round mean', round(g[26] / R), 'rounds whose slowest wave re-reduced', round(g[27] / R, 3))
+        print('   slowest wave by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF): share', [round(g[k] / R, 3) for k in range(8)], 'its time', [round(g[8 + k] / max(1, g[k])) for k in range(8)], 'lead over 2nd', [round(g[16 + k] / max(1, g[k])) for k in range(8)])
+        print('   step time by kernel, all waves:', [round(g[36 + k] / max(1, g[28 + k])) for k in range(8)], 'share of steps', [round(g[28 + k] / max(1, sum(g[28:36])), 3) for k in range(8)], 're-reducing steps: share', round(g[44] / max(1, sum(g[28:36])), 3), 'time', round(g[45] / max(1, g[44])))
     print('spec', spec, 'lanes', lanes, 'kernel ms', ctx.last_kernel_ms(), {n: round(x/100001) for n, x in zip(names, v)}, 'sum', round(v.sum()/100001), 'clock64 ticks/step')
