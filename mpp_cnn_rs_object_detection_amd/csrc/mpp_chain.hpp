@@ -120,6 +120,12 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
 // the pair terms' parameters, read ONCE per launch into registers: inside the non-unrolled loops of eval_delta every
 // P->model.pair[p].field was a scalar load followed by a wait (the chain kernel is built without machine LICM)
 struct PairRegs { int kind, reduce, maxd2, gated; double coef, p0, max_dist; };
+// The grid facts every step asks for many times.  The parameter block lives in the kernel-argument segment, every
+// P->field in the step loop is a scalar load (the kernel is built without machine LICM), and a scalar load's wait --
+// s_waitcnt lgkmcnt(0): scalar loads return out of order -- also drains every LDS read in flight.  These seven are read
+// ONCE per launch and laundered through an empty asm, so the compiler can neither re-load them nor hoist anything: they
+// stay in scalar registers (or in lanes of a spill register, which costs a v_readlane, not a memory wait).
+struct HotP { int H, W, nx, ny, cell_cap, res_shift, res_int; };
 struct Chain {
   const DevParams *P;
   TileRef t;
@@ -127,7 +133,18 @@ struct Chain {
   int lane, wave;
   int np, comb;
   PairRegs pr0, pr1;
+  HotP h;
 };
+__device__ __forceinline__ int launder_s(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ void load_hot(Chain &c) {
+  const DevParams *Q = c.P;
+  c.h.H = launder_s(Q->H); c.h.W = launder_s(Q->W); c.h.nx = launder_s(Q->nx); c.h.ny = launder_s(Q->ny);
+  c.h.cell_cap = launder_s(Q->cell_cap); c.h.res_shift = launder_s(Q->res_shift); c.h.res_int = launder_s(Q->res_int);
+}
 __device__ __forceinline__ PairRegs load_pair_regs(const DevParams *P, int p) {
   PairRegs r;
   const mpp_pair_term &t = P->model.pair[p];
@@ -171,13 +188,13 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-__device__ __forceinline__ int cell_coord(const DevParams *P, int x) {
-  return P->res_shift >= 0 ? (x >> P->res_shift) : (x / P->res_int);
+__device__ __forceinline__ int cell_coord(const Chain &c, int x) {
+  return c.h.res_shift >= 0 ? (x >> c.h.res_shift) : (x / c.h.res_int);
 }
-__device__ __forceinline__ int cell_index(const DevParams *P, int x, int y, int *ci, int *cj) {
-  int i = cell_coord(P, x), j = cell_coord(P, y);
+__device__ __forceinline__ int cell_index(const Chain &c, int x, int y, int *ci, int *cj) {
+  int i = cell_coord(c, x), j = cell_coord(c, y);
   *ci = i; *cj = j;
-  return j + i * P->ny;
+  return j + i * c.h.ny;
 }
 struct Geo2 { Geo g; double rad; };
 __device__ __forceinline__ Geo2 load_geo(const Lds &L, int slot) {
@@ -362,7 +379,7 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
   const Lds &L = c.L;
   const PairRegs pt = pair_regs(c, p);
   int ci, cj;
-  cell_index(P, gu.g.x, gu.g.y, &ci, &cj);
+  cell_index(c, gu.g.x, gu.g.y, &ci, &cj);
   double acc = 0.0;
 #ifdef MPP_PROFILE
   if (c.wave == 0) atomicAdd(&g_prof2[10], 1ull);
@@ -370,10 +387,10 @@ __device__ double rescan_lane(const Chain &c, int p, int u, const Geo2 &gu, int 
   for (int di = -1; di <= 1; ++di)
     for (int dj = -1; dj <= 1; ++dj) {
       int i = ci + di, j = cj + dj;
-      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
-      int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      if (i < 0 || i >= c.h.nx || j < 0 || j >= c.h.ny) continue;
+      int cell = j + i * c.h.ny, cnt = L.cell_cnt[cell];
       for (int e = 0; e < cnt; ++e) {
-        int w = L.cell_items[cell * P->cell_cap + e];
+        int w = L.cell_items[cell * c.h.cell_cap + e];
         if (w == u || w == skip) continue;
         int wxy = L.xy[w];
         int dx = gu.g.x - (wxy & 0xffff), dy = gu.g.y - ((wxy >> 16) & 0xffff), d2 = dx * dx + dy * dy;
@@ -423,8 +440,8 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
   else { gr = ag; rr = ar; }
   int cir = 0, cjr = 0, cia = 0, cja = 0;
-  if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
-  if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
+  if (has_rem) cell_index(c, gr.g.x, gr.g.y, &cir, &cjr);
+  if (has_add) cell_index(c, ag.g.x, ag.g.y, &cia, &cja);
 
   // ---- the 3x3 cells around the removed and the added point.  Lane 3k+e (k < 18, e < 3) owns entry e of cell k:
   // with at most 3 points in each of the 18 cells (the usual case) every candidate neighbour has its lane
@@ -437,7 +454,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     int i = (second ? cia : cir) + k / 3 - 1, j = (second ? cja : cjr) + k % 3 - 1;
     bool ok = second ? has_add : has_rem;
     if (ok && second && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) ok = false;   // already listed
-    if (ok && i >= 0 && i < P->nx && j >= 0 && j < P->ny) my_cell = j + i * P->ny;
+    if (ok && i >= 0 && i < c.h.nx && j >= 0 && j < c.h.ny) my_cell = j + i * c.h.ny;
   }
   const int my_cnt = my_cell >= 0 ? (int)L.cell_cnt[my_cell] : 0;
   const bool direct = __ballot(my_cnt > 3) == 0ull;
@@ -454,7 +471,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   bool any_changed = false, any_a = false;
   int stash_n = 0;
   for (int base = 0; base < M; base += WAVE) {
-    int my_base = my_cell * P->cell_cap, my_e = ce;
+    int my_base = my_cell * c.h.cell_cap, my_e = ce;
     bool active = ce < my_cnt;
     if (!direct) {
       const int j = base + c.lane;
@@ -464,7 +481,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
       for (int k = 0; k < 18; ++k) {
         int cnt_k = __builtin_amdgcn_readlane(my_cnt, 3 * k);
         int cell_k = __builtin_amdgcn_readlane(my_cell, 3 * k);
-        if (j >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * P->cell_cap; }
+        if (j >= lo && cnt_k > 0) { my_lo = lo; my_base = cell_k * c.h.cell_cap; }
         lo += cnt_k;
       }
       active = j < M;
@@ -617,11 +634,11 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
         bu.g.hl = readlane_d(gu.g.hl, src); bu.g.hw = readlane_d(gu.g.hw, src);
         bu.g.ca = readlane_d(gu.g.ca, src); bu.g.sa = readlane_d(gu.g.sa, src); bu.rad = readlane_d(gu.rad, src);
         int uci, ucj;
-        cell_index(P, bu.g.x, bu.g.y, &uci, &ucj);
+        cell_index(c, bu.g.x, bu.g.y, &uci, &ucj);
         int cell2 = -1;
         if (ck < 9) {
           const int i = uci + ck / 3 - 1, j = ucj + ck % 3 - 1;
-          if (i >= 0 && i < P->nx && j >= 0 && j < P->ny) cell2 = j + i * P->ny;
+          if (i >= 0 && i < c.h.nx && j >= 0 && j < c.h.ny) cell2 = j + i * c.h.ny;
         }
         const int cnt2 = cell2 >= 0 ? (int)L.cell_cnt[cell2] : 0;
         const bool direct2 = __ballot(cnt2 > 3) == 0ull;
@@ -634,7 +651,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
         const double rew = f1.p0 != 0.0 ? 1.0 : 0.0, Au = geo_area(bu.g);
         double acc0 = 0.0, acc1 = 0.0;                     // wave-uniform results
         for (int base2 = 0; base2 < M2; base2 += WAVE) {
-          int it_base = cell2 * P->cell_cap, it_e = ce;
+          int it_base = cell2 * c.h.cell_cap, it_e = ce;
           bool act2 = ce < cnt2;
           if (!direct2) {
             const int j = base2 + c.lane;
@@ -643,7 +660,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
               const int cnt_k = __builtin_amdgcn_readlane(cnt2, 3 * k), cell_k = __builtin_amdgcn_readlane(cell2, 3 * k);
-              if (j >= lo && cnt_k > 0) { my_lo = lo; it_base = cell_k * P->cell_cap; }
+              if (j >= lo && cnt_k > 0) { my_lo = lo; it_base = cell_k * c.h.cell_cap; }
               lo += cnt_k;
             }
             act2 = j < M2;
@@ -790,7 +807,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
 // sums it in index order -- no cross-lane traffic, wave-uniform result, same order as the oracle.
 // Returns P[cls]/sum; with `draw` the class is first drawn: #{j : cumsum_j <= u*sum}.
 __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool draw, double u, int *drawn) {
-  const float4 *row = (const float4 *)mark_row(c.P, c.t, k, x, y);
+  const float4 *row = (const float4 *)mark_row_w(c.h.W, c.t, k, x, y);
   float v[MPP_NCLASS];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { float4 q = row[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
@@ -815,7 +832,7 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
 // calls in a row -- and collected with readlane: one row latency and one pass of arithmetic instead of three.
 __device__ double birth_density(const Chain &c, const Rect &q, bool coop) {
   const DevParams *P = c.P;
-  double d = (double)c.t.det[(size_t)q.x * P->W + q.y] / (c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H]);
+  double d = (double)c.t.det[(size_t)q.x * c.h.W + q.y] / (c.L.rowbase ? c.L.rowbase[c.h.H] : c.t.rowbase[c.h.H]);
   if (coop) {
     const int kk = c.lane < 2 ? c.lane : 2;
     const double pl = row_prob(c, kk, q.x, q.y, value_to_class_tab(P, c.L.edges + kk * MPP_NCLASS, kk, mark_of(q, kk)),
@@ -826,7 +843,7 @@ __device__ double birth_density(const Chain &c, const Rect &q, bool coop) {
     for (int k = 0; k < 3; ++k)
       d *= row_prob(c, k, q.x, q.y, value_to_class_tab(P, c.L.edges + k * MPP_NCLASS, k, mark_of(q, k)), false, 0.0, nullptr);
   }
-  return d * ((double)P->H * (double)P->W * 32768.0);
+  return d * ((double)c.h.H * (double)c.h.W * 32768.0);
 }
 // data-driven translation (transform_kernels.py:77-89): draw a pixel of the (2*max_delta+1)^2 window
 // around (x,y) with probability det/sum.  Lane i owns window row i (<= 31 rows): its segment sum comes
@@ -834,12 +851,12 @@ __device__ double birth_density(const Chain &c, const Rect &q, bool coop) {
 __device__ void window_draw(const Chain &c, int x, int y, double u, int *ex, int *ey) {
   const DevParams *P = c.P;
   const int md = P->kern.max_delta;
-  const int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
+  const int x0 = max(0, x - md), x1 = min(x + md + 1, c.h.H), y0 = max(0, y - md), y1 = min(y + md + 1, c.h.W);
   const int nrow = x1 - x0, wc = y1 - y0;
-  const double tot = c.t.boxsum[(size_t)x * P->W + y];
+  const double tot = c.t.boxsum[(size_t)x * c.h.W + y];
   double seg = 0.0;
   if (c.lane < nrow) {
-    const double *rp = c.t.rowpart + (size_t)(x0 + c.lane) * P->W;
+    const double *rp = c.t.rowpart + (size_t)(x0 + c.lane) * c.h.W;
     seg = rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0);
   }
   double before = 0.0;          // sum of the rows above the chosen one
@@ -849,7 +866,7 @@ __device__ void window_draw(const Chain &c, int x, int y, double u, int *ex, int
     double nxt = before + readlane_d(seg, i);
     if (nxt <= thr && i < nrow - 1) { before = nxt; row = i + 1; } else break;
   }
-  const double *rp = c.t.rowpart + (size_t)(x0 + row) * P->W;
+  const double *rp = c.t.rowpart + (size_t)(x0 + row) * c.h.W;
   const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
   bool le = false;
   if (c.lane < wc) le = (before + (rp[y0 + c.lane] - lead)) <= thr;
@@ -895,8 +912,8 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
   if (has_rem) { gr = load_geo(L, rem); rr = load_rect(L, rem); }
   else { gr = ag; rr = ar; }
   int cir = 0, cjr = 0, cia = 0, cja = 0;
-  if (has_rem) cell_index(P, gr.g.x, gr.g.y, &cir, &cjr);
-  if (has_add) cell_index(P, ag.g.x, ag.g.y, &cia, &cja);
+  if (has_rem) cell_index(c, gr.g.x, gr.g.y, &cir, &cjr);
+  if (has_add) cell_index(c, ag.g.x, ag.g.y, &cia, &cja);
   double sum_de = 0.0, ra[2] = {0.0, 0.0};
   int stash_n = 0;
   for (int pass = 0; pass < 2; ++pass) {
@@ -904,11 +921,11 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
     const int ci0 = pass == 0 ? cir : cia, cj0 = pass == 0 ? cjr : cja;
     for (int k = 0; k < 9; ++k) {
       int i = ci0 + k / 3 - 1, j = cj0 + k % 3 - 1;
-      if (i < 0 || i >= P->nx || j < 0 || j >= P->ny) continue;
+      if (i < 0 || i >= c.h.nx || j < 0 || j >= c.h.ny) continue;
       if (pass == 1 && has_rem && abs(i - cir) <= 1 && abs(j - cjr) <= 1) continue;     // already visited
-      const int cell = j + i * P->ny, cnt = L.cell_cnt[cell];
+      const int cell = j + i * c.h.ny, cnt = L.cell_cnt[cell];
       for (int e = 0; e < cnt; ++e) {
-        const int u = L.cell_items[cell * P->cell_cap + e];
+        const int u = L.cell_items[cell * c.h.cell_cap + e];
         if (u == rem) continue;
         const int uxy = L.xy[u];
         const int ux = uxy & 0xffff, uy = (uxy >> 16) & 0xffff;
@@ -989,18 +1006,18 @@ __device__ int count_le_8ary(int n, F key_le) {
 __device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex, int *ey) {
   const DevParams *P = c.P;
   const int md = P->kern.max_delta;
-  const int x0 = max(0, x - md), x1 = min(x + md + 1, P->H), y0 = max(0, y - md), y1 = min(y + md + 1, P->W);
+  const int x0 = max(0, x - md), x1 = min(x + md + 1, c.h.H), y0 = max(0, y - md), y1 = min(y + md + 1, c.h.W);
   const int nrow = x1 - x0, wc = y1 - y0;
-  const double tot = c.t.boxsum[(size_t)x * P->W + y];
+  const double tot = c.t.boxsum[(size_t)x * c.h.W + y];
   double before = 0.0;
   const double thr = u * tot;
   int row = 0;
   for (int i = 0; i < nrow; ++i) {
-    const double *rp = c.t.rowpart + (size_t)(x0 + i) * P->W;
+    const double *rp = c.t.rowpart + (size_t)(x0 + i) * c.h.W;
     double nxt = before + (rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0));
     if (nxt <= thr && i < nrow - 1) { before = nxt; row = i + 1; } else break;
   }
-  const double *rp = c.t.rowpart + (size_t)(x0 + row) * P->W;
+  const double *rp = c.t.rowpart + (size_t)(x0 + row) * c.h.W;
   const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
   int col = 0;
   for (int jj = 0; jj < wc; ++jj) col += ((before + (rp[y0 + jj] - lead)) <= thr) ? 1 : 0;
@@ -1035,7 +1052,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
   *keep = 0;
   if (k == MPP_K_UBIRTH) {
     r.has_add = 1;
-    r.ax = (int)mulhi32(w[3], (uint32_t)P->H); r.ay = (int)mulhi32(w[4], (uint32_t)P->W);
+    r.ax = (int)mulhi32(w[3], (uint32_t)c.h.H); r.ay = (int)mulhi32(w[4], (uint32_t)c.h.W);
     r.as = P->maps.vmin[0] + (P->maps.vmax[0] - P->maps.vmin[0]) * u32d(w[5]);
     r.ar = P->maps.vmin[1] + (P->maps.vmax[1] - P->maps.vmin[1]) * u32d(w[6]);
     r.aa = P->maps.vmin[2] + (P->maps.vmax[2] - P->maps.vmin[2]) * u32d(w[7]);
@@ -1044,7 +1061,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
 #ifdef MPP_EXP_CHEAPDB         /* timing experiment only: a data-driven birth that costs what a uniform one does (wrong chain) */
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
-    r.ax = (int)mulhi32(w[3], (uint32_t)P->H); r.ay = (int)mulhi32(w[4], (uint32_t)P->W);
+    r.ax = (int)mulhi32(w[3], (uint32_t)c.h.H); r.ay = (int)mulhi32(w[4], (uint32_t)c.h.W);
     r.as = c.L.edges[(int)mulhi32(w[5], 32u)]; r.ar = c.L.edges[MPP_NCLASS + (int)mulhi32(w[6], 32u)]; r.aa = c.L.edges[2 * MPP_NCLASS + (int)mulhi32(w[7], 32u)];
     r.qf = 1.0; *keep = KEEP_QF;
     return;
@@ -1052,46 +1069,46 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
 #endif
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
-    const double u = u53(w[3], w[4]), tot = c.L.rowbase ? c.L.rowbase[P->H] : c.t.rowbase[P->H];
+    const double u = u53(w[3], w[4]), tot = c.L.rowbase ? c.L.rowbase[c.h.H] : c.t.rowbase[c.h.H];
     const double thr = u * tot;                       // cdf <= u <=> partial sum <= u*total
     int row = 0, col = 0;                             // #rows / #columns whose inclusive cdf is <= u (monotone)
     if (LANE) {
       const double *rb = c.L.rowbase ? c.L.rowbase : c.t.rowbase;
-      row = count_le_8ary(P->H, [&](int i) { return rb[i + 1] <= thr; });
-      if (row >= P->H) row = P->H - 1;
+      row = count_le_8ary(c.h.H, [&](int i) { return rb[i + 1] <= thr; });
+      if (row >= c.h.H) row = c.h.H - 1;
       const double base = rb[row];
-      const double *part = c.t.rowpart + (size_t)row * P->W;
-      col = count_le_8ary(P->W, [&](int j) { return (base + part[j]) <= thr; });
+      const double *part = c.t.rowpart + (size_t)row * c.h.W;
+      col = count_le_8ary(c.h.W, [&](int j) { return (base + part[j]) <= thr; });
     } else {
       // counts of a monotone table: the loads of a chunk are issued together (8 per lane), then counted -- one memory
       // latency per 512 entries instead of one per 64.  The row level sits in LDS when it fits (H <= 1024).
       double base = 0.0;
       auto row_search = [&](auto rb) {
-        for (int i0 = 0; i0 < P->H; i0 += 8 * WAVE) {
+        for (int i0 = 0; i0 < c.h.H; i0 += 8 * WAVE) {
           double v[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) { int i = i0 + k * WAVE + c.lane; v[k] = i < P->H ? rb[i + 1] : INFINITY; }
+          for (int k = 0; k < 8; ++k) { int i = i0 + k * WAVE + c.lane; v[k] = i < c.h.H ? rb[i + 1] : INFINITY; }
 #pragma unroll
           for (int k = 0; k < 8; ++k) row += __popcll(__ballot(v[k] <= thr));
         }
-        if (row >= P->H) row = P->H - 1;
+        if (row >= c.h.H) row = c.h.H - 1;
         base = rb[row];
       };
       if (c.L.rowbase) row_search(c.L.rowbase); else row_search(c.t.rowbase);
-      const MPP_GLOBAL double *part = c.t.rowpart + (size_t)row * P->W;
-      for (int j0 = 0; j0 < P->W; j0 += 8 * WAVE) {
+      const MPP_GLOBAL double *part = c.t.rowpart + (size_t)row * c.h.W;
+      for (int j0 = 0; j0 < c.h.W; j0 += 8 * WAVE) {
         double v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { int j = j0 + k * WAVE + c.lane; v[k] = j < P->W ? part[j] : INFINITY; }
+        for (int k = 0; k < 8; ++k) { int j = j0 + k * WAVE + c.lane; v[k] = j < c.h.W ? part[j] : INFINITY; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) col += __popcll(__ballot((base + v[k]) <= thr));
       }
     }
-    if (col >= P->W) col = P->W - 1;
+    if (col >= c.h.W) col = c.h.W - 1;
     r.ax = row; r.ay = col;
     // marks, and on the way the birth density of the drawn point (shape_samplers.py:103-108; same operation
     // order as birth_density())
-    double d = (double)c.t.det[(size_t)row * P->W + col] / tot;
+    double d = (double)c.t.det[(size_t)row * c.h.W + col] / tot;
     const uint32_t w5 = w[5], w6 = w[6], w7 = w[7];
     if (LANE) {
 #pragma clang loop unroll(disable)
@@ -1110,7 +1127,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
       d *= readlane_d(pl, 0); d *= readlane_d(pl, 1); d *= readlane_d(pl, 2);
       r.as = c.L.edges[c0]; r.ar = c.L.edges[MPP_NCLASS + c1]; r.aa = c.L.edges[2 * MPP_NCLASS + c2];
     }
-    r.qf = d * ((double)P->H * (double)P->W * 32768.0);
+    r.qf = d * ((double)c.h.H * (double)c.h.W * 32768.0);
     *keep = KEEP_QF;
     return;
   }
@@ -1130,7 +1147,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
   if (k == MPP_K_GTRANS) {
     double d0 = P->kern.sigma_trans * z0, d1 = P->kern.sigma_trans * z1;
     int nx = (int)((double)q.x + d0), ny = (int)((double)q.y + d1);
-    q.x = min(max(nx, 0), P->H - 1); q.y = min(max(ny, 0), P->W - 1);
+    q.x = min(max(nx, 0), c.h.H - 1); q.y = min(max(ny, 0), c.h.W - 1);
     r.aux0 = d0; r.aux1 = d1;
     *keep = KEEP_TRIG | KEEP_SIZE;
   } else if (k == MPP_K_DTRANS) {
@@ -1177,8 +1194,8 @@ __device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int kee
       break;
     case MPP_K_DTRANS:
       if (r.has_rem) {        // transform_kernels.py:94-99: window renormalised around start resp. end
-        r.qf = (double)c.t.det[(size_t)r.ax * P->W + r.ay] / c.t.boxsum[(size_t)r.rx * P->W + r.ry];
-        r.qb = (double)c.t.det[(size_t)r.rx * P->W + r.ry] / c.t.boxsum[(size_t)r.ax * P->W + r.ay];
+        r.qf = (double)c.t.det[(size_t)r.ax * c.h.W + r.ay] / c.t.boxsum[(size_t)r.rx * c.h.W + r.ry];
+        r.qb = (double)c.t.det[(size_t)r.rx * c.h.W + r.ry] / c.t.boxsum[(size_t)r.ax * c.h.W + r.ay];
       }
       break;
     case MPP_K_GTRANSF:
@@ -1189,7 +1206,7 @@ __device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int kee
       if (r.has_rem) {
         Rect old = load_rect(c.L, r.tslot);
         int oc = value_to_class_tab(P, c.L.edges + r.pid * MPP_NCLASS, r.pid, mark_of(old, r.pid));
-        const float *row = mark_row(P, c.t, r.pid, old.x, old.y);
+        const float *row = mark_row_w(c.h.W, c.t, r.pid, old.x, old.y);
         // both classes of the same row: P[new]/sum and P[old]/sum (one row read)
         double tot = 0.0;
         for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)row[i];
@@ -1221,7 +1238,7 @@ __device__ __forceinline__ void green_terms(const DevParams *P, const Rec &r, in
 __device__ void cell_remove(const Chain &c, int cell, int slot) {
   const Lds &L = c.L;
   int cnt = L.cell_cnt[cell];
-  unsigned short *it = L.cell_items + (size_t)cell * c.P->cell_cap;
+  unsigned short *it = L.cell_items + (size_t)cell * c.h.cell_cap;
   unsigned long long m = __ballot(c.lane < cnt && it[c.lane] == slot);
   wave_lds_fence();
   if (m && c.lane == 0) {
@@ -1234,9 +1251,9 @@ __device__ void cell_remove(const Chain &c, int cell, int slot) {
 __device__ void cell_insert(const Chain &c, int cell, int slot, int *err) {
   const Lds &L = c.L;
   int cnt = L.cell_cnt[cell];
-  if (cnt >= c.P->cell_cap) { *err = ERR_CELL_OVERFLOW; return; }
+  if (cnt >= c.h.cell_cap) { *err = ERR_CELL_OVERFLOW; return; }
   if (c.lane == 0) {
-    L.cell_items[(size_t)cell * c.P->cell_cap + cnt] = (unsigned short)slot;
+    L.cell_items[(size_t)cell * c.h.cell_cap + cnt] = (unsigned short)slot;
     L.cell_cnt[cell] = (unsigned short)(cnt + 1);
   }
   wave_lds_fence();
@@ -1269,7 +1286,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
   // the score-map values of the proposed rectangle: requested first, used after the densities and the trigonometry
   MapVals mv{0.f, 0.f, 0.f, 0.f};
 #ifndef MPP_NO_HOIST
-  if (r.has_add) mv = load_map_vals(P, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
+  if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
 #endif
   proposal_densities(c, r, tracing, keep, !LANE);
   EPROF(4);
@@ -1290,7 +1307,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
       else { double al = add.a + MPP_PI / 2.0; ag.g.ca = cos(al); ag.g.sa = sin(al); }
       EPROF(5);
 #ifdef MPP_NO_HOIST
-      mv = load_map_vals(P, c.t, L.edges, add);
+      mv = load_map_vals_w(P, c.h.W, c.t, L.edges, add);
 #endif
       unit_part_mv(P, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
       r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;

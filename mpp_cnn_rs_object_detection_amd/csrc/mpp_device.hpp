@@ -209,22 +209,29 @@ __device__ __forceinline__ void set_mark(Rect &q, int k, double v) {
   const double s = q.s, r = q.r, a = q.a;
   q.s = k == 0 ? v : s; q.r = k == 1 ? v : r; q.a = k == 2 ? v : a;
 }
-__device__ __forceinline__ const float *mark_row(const DevParams *P, const TileRef &t, int k, int x, int y) {
+__device__ __forceinline__ const float *mark_row_w(int W, const TileRef &t, int k, int x, int y) {
   const float *m0 = t.m[0], *m1 = t.m[1], *m2 = t.m[2];
   const float *b = k == 0 ? m0 : (k == 1 ? m1 : m2);   // no runtime-indexed private array
-  return b + ((size_t)x * P->W + y) * MPP_NCLASS;
+  return b + ((size_t)x * W + y) * MPP_NCLASS;
+}
+__device__ __forceinline__ const float *mark_row(const DevParams *P, const TileRef &t, int k, int x, int y) {
+  return mark_row_w(P->W, t, k, x, y);
 }
 
 // the score-map values a rectangle's unit terms can ask for: det at its pixel and, per mark, the probability of the
 // mark's class there.  Fetched together (four independent loads, one memory latency) before the terms are evaluated.
 struct MapVals { float det, m0, m1, m2; };
-__device__ __forceinline__ MapVals load_map_vals(const DevParams *P, const TileRef &t, const double *edges, const Rect &q) {
-  const size_t px = (size_t)q.x * P->W + q.y, pix = px * MPP_NCLASS;
+// (W: the tile width, passed separately so that the chain can hand over its register copy instead of a scalar load)
+__device__ __forceinline__ MapVals load_map_vals_w(const DevParams *P, int W, const TileRef &t, const double *edges, const Rect &q) {
+  const size_t px = (size_t)q.x * W + q.y, pix = px * MPP_NCLASS;
   const int c0 = value_to_class_tab(P, edges, 0, q.s), c1 = value_to_class_tab(P, edges + MPP_NCLASS, 1, q.r),
             c2 = value_to_class_tab(P, edges + 2 * MPP_NCLASS, 2, q.a);
   MapVals v;
   v.det = t.det[px]; v.m0 = t.m[0][pix + c0]; v.m1 = t.m[1][pix + c1]; v.m2 = t.m[2][pix + c2];
   return v;
+}
+__device__ __forceinline__ MapVals load_map_vals(const DevParams *P, const TileRef &t, const double *edges, const Rect &q) {
+  return load_map_vals_w(P, P->W, t, edges, q);
 }
 __device__ __forceinline__ float map_mark(const MapVals &v, int k) {
   const float a = v.m0, b = v.m1, c = v.m2;

@@ -32,6 +32,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   Chain c;
   c.P = P; c.t = tiles[tile];
   load_model_regs(c);
+  load_hot(c);
   const int ncell = P->nx * P->ny, cap = P->cap;
   const int rowbase_n = P->rowbase_lds ? P->H + 1 : 0;
   c.L = carve(lds_raw, cap, ncell, P->cell_cap, SPEC, rowbase_n, WAVES);
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   if (tid == 0) {                               // serial: keeps the cell order, hence the result, deterministic
     for (int i = 0; i < n0; ++i) {
       int xy = L.xy[i], ci, cj;
-      int cell = cell_index(P, xy & 0xffff, (xy >> 16) & 0xffff, &ci, &cj);
+      int cell = cell_index(c, xy & 0xffff, (xy >> 16) & 0xffff, &ci, &cj);
       int cnt = L.cell_cnt[cell];
       if (cnt >= P->cell_cap) { err = ERR_CELL_OVERFLOW; break; }
       L.cell_items[(size_t)cell * P->cell_cap + cnt] = (unsigned short)i;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0 && r.kernel >= 0 && r.kernel < 8) atomicAdd(&g_prof4[r.kernel], n_ - pt_); }
 #endif
       PROF_ADD(0);
-      if (r.valid && r.has_add && (r.ax < 0 || r.ax >= P->H || r.ay < 0 || r.ay >= P->W)) { r.valid = 0; r.kernel = -1; }
+      if (r.valid && r.has_add && (r.ax < 0 || r.ax >= c.h.H || r.ay < 0 || r.ay >= c.h.W)) { r.valid = 0; r.kernel = -1; }
       if (SM && r.valid && r.kernel >= MPP_K_SPLIT && r.has_rem) {
         // a two-point change runs alone on the live state: ask for an apply round, or (in it) do the whole step
         r.dE = 0.0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         const int m_kern = me.kernel, m_hr = me.has_rem, m_ha = me.has_add, m_ts = me.tslot, m_nst = me.n_stash, m_pad = me._pad;
         const int m_rx = me.rx, m_ry = me.ry, m_ax = me.ax, m_ay = me.ay;
         int ci, cj;
-        const int m_cr = m_hr ? cell_index(P, m_rx, m_ry, &ci, &cj) : -1, m_ca = m_ha ? cell_index(P, m_ax, m_ay, &ci, &cj) : -2;
+        const int m_cr = m_hr ? cell_index(c, m_rx, m_ry, &ci, &cj) : -1, m_ca = m_ha ? cell_index(c, m_ax, m_ay, &ci, &cj) : -2;
         const unsigned long long acc_mask = __ballot(in && me.accepted && (m_hr || m_ha));
         unsigned int commit_mask = 0;
         int cur = 0;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           // re-launch with a larger capacity continues it as if there had been no limit.  (Cell counts are those of
           // the round's start: an earlier commit of this round that touched the same cell has invalidated record w.)
           const int q_ca_w = __builtin_amdgcn_readlane(m_ca, w), q_cr_w = __builtin_amdgcn_readlane(m_cr, w);
-          if (q_ha && q_ca_w != q_cr_w && (int)L.cell_cnt[q_ca_w] >= P->cell_cap) { err = ERR_CELL_OVERFLOW; committed = w; break; }
+          if (q_ha && q_ca_w != q_cr_w && (int)L.cell_cnt[q_ca_w] >= c.h.cell_cap) { err = ERR_CELL_OVERFLOW; committed = w; break; }
           if (!(q_hr && q_ha)) {                                                 // death / birth: ends the round
             if (q_hr) { commit_mask |= 1u << w; cur_n -= 1; }
             else if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; committed = w; break; }
@@ -334,11 +335,11 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         wave_lds_fence();
         int ci, cj;
         if (q.has_rem && q.has_add) {                      // move / transform: same slot
-          int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
+          int c0 = cell_index(c, q.rx, q.ry, &ci, &cj), c1 = cell_index(c, q.ax, q.ay, &ci, &cj);
           if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &e2); }
           write_slot(c, q.tslot, q);
         } else if (q.has_rem) {                            // death: last index takes the hole
-          cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
+          cell_remove(c, cell_index(c, q.rx, q.ry, &ci, &cj), q.tslot);
           if (c.lane == 0) {
             unsigned short last = L.order[n - 1];
             L.order[n - 1] = (unsigned short)q.tslot;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           }
         } else {                                           // birth: next free slot
           int slot = L.order[n];
-          cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &e2);
+          cell_insert(c, cell_index(c, q.ax, q.ay, &ci, &cj), slot, &e2);
           write_slot(c, slot, q);
         }
         if (e2 && c.lane == 0) L.sh[1] = e2;
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         if (SM && q._pad != 0) { cur_n += q._pad; return true; }      // a split / merge applied by sm_step()
         if (q.has_add) {                                   // capacity checks before anything is applied (see above)
           int ci, cj;
-          const int c1 = cell_index(P, q.ax, q.ay, &ci, &cj), c0 = q.has_rem ? cell_index(P, q.rx, q.ry, &ci, &cj) : -1;
-          if (c1 != c0 && (int)L.cell_cnt[c1] >= P->cell_cap) { err = ERR_CELL_OVERFLOW; return true; }
+          const int c1 = cell_index(c, q.ax, q.ay, &ci, &cj), c0 = q.has_rem ? cell_index(c, q.rx, q.ry, &ci, &cj) : -1;
+          if (c1 != c0 && (int)L.cell_cnt[c1] >= c.h.cell_cap) { err = ERR_CELL_OVERFLOW; return true; }
           if (!q.has_rem && cur_n >= cap) { err = ERR_POINT_OVERFLOW; return true; }
         }
         if (!apply_round && c.lane < q.n_stash) {
@@ -376,12 +377,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         bool stop = false;
         if (q.has_rem && q.has_add) {                      // move / transform: same slot
           int ci, cj;
-          int c0 = cell_index(P, q.rx, q.ry, &ci, &cj), c1 = cell_index(P, q.ax, q.ay, &ci, &cj);
+          int c0 = cell_index(c, q.rx, q.ry, &ci, &cj), c1 = cell_index(c, q.ax, q.ay, &ci, &cj);
           if (c0 != c1) { cell_remove(c, c0, q.tslot); cell_insert(c, c1, q.tslot, &err); }
           write_slot(c, q.tslot, q);
         } else if (q.has_rem) {                            // death: last index takes the hole
           int ci, cj;
-          cell_remove(c, cell_index(P, q.rx, q.ry, &ci, &cj), q.tslot);
+          cell_remove(c, cell_index(c, q.rx, q.ry, &ci, &cj), q.tslot);
           if (c.lane == 0) {
             unsigned short last = L.order[cur_n - 1];
             L.order[cur_n - 1] = (unsigned short)q.tslot;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; }
           else {
             int slot = L.order[cur_n], ci, cj;
-            cell_insert(c, cell_index(P, q.ax, q.ay, &ci, &cj), slot, &err);
+            cell_insert(c, cell_index(c, q.ax, q.ay, &ci, &cj), slot, &err);
             write_slot(c, slot, q);
             cur_n += 1;
           }

@@ -56,7 +56,7 @@ __device__ inline int sm_count_potential(const Chain &c, int x, int y) {
   const DevParams *P = c.P;
   const int off = (int)ceil(P->kern.split_radius / P->res);
   int ci, cj, cnt = 0;
-  cell_index(P, x, y, &ci, &cj);
+  cell_index(c, x, y, &ci, &cj);
   for (int di = -off; di <= off; ++di)
     for (int dj = -off; dj <= off; ++dj) {
       int i = ci + di, j = cj + dj;
@@ -74,7 +74,7 @@ __device__ inline int sm_neighbours(const Chain &c, int ri, int slot0, int x0, i
   const int off = (int)ceil(R / P->res);
   const unsigned long long below = (1ull << c.lane) - 1ull;
   int ci, cj, cnt = 0;
-  cell_index(P, x0, y0, &ci, &cj);
+  cell_index(c, x0, y0, &ci, &cj);
   for (int di = -off; di <= off; ++di)
     for (int dj = -off; dj <= off; ++dj) {
       int i = ci + di, j = cj + dj;
@@ -195,10 +195,10 @@ __device__ inline double sm_place(const Chain &c, int slot, bool moving, const R
   const double dE = eval_delta(c, 0, moving ? slot : -1, true, q, ag, lin_a, gate_a, &ra0, &ra1, &n_stash, true);
   wave_lds_fence();
   int ci, cj;
-  const int c1 = cell_index(P, q.x, q.y, &ci, &cj);
+  const int c1 = cell_index(c, q.x, q.y, &ci, &cj);
   if (moving) {
     const int oxy = L.xy[slot];
-    const int c0 = cell_index(P, oxy & 0xffff, (oxy >> 16) & 0xffff, &ci, &cj);
+    const int c0 = cell_index(c, oxy & 0xffff, (oxy >> 16) & 0xffff, &ci, &cj);
     if (c0 != c1) { cell_remove(c, c0, slot); cell_insert(c, c1, slot, err); }
   } else {
     cell_insert(c, c1, slot, err);
@@ -224,7 +224,7 @@ __device__ inline double sm_remove(const Chain &c, int slot) {
   const double dE = eval_delta(c, 0, slot, false, none, ag, 0.0, 1, &ra0, &ra1, &n_stash, true);
   wave_lds_fence();
   const int xy = L.xy[slot];
-  cell_remove(c, cell_index(P, xy & 0xffff, (xy >> 16) & 0xffff, &ci, &cj), slot);
+  cell_remove(c, cell_index(c, xy & 0xffff, (xy >> 16) & 0xffff, &ci, &cj), slot);
   return dE;
 }
 
