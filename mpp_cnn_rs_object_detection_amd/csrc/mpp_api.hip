@@ -10,6 +10,7 @@
 #include "mpp_device.hpp"
 
 extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves);
+extern "C" size_t mpp_chain_static_lds_bytes(int waves);
 extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int occ, int grid, size_t lds,
                                        const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
                                        long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
@@ -257,7 +258,8 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
     int ncell = c->hp.nx * c->hp.ny;
     int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
     int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
-    return (int64_t)mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
+    return (int64_t)(mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec) +
+                     mpp_chain_static_lds_bytes(c->lanes > 0 ? 4 : c->spec));
   }
   return -1;
 }
@@ -731,6 +733,10 @@ static size_t chain_lds(mpp_ctx *c, int cap, int cell_cap) {
   const int rb = c->hp.rowbase_lds ? c->H + 1 : 0;
   return mpp_chain_lds_bytes(cap, ncell, cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec);
 }
+// dynamic + static LDS of a chain: what has to fit the 160 KB of a CU
+static size_t chain_lds_total(mpp_ctx *c, int cap, int cell_cap) {
+  return chain_lds(c, cap, cell_cap) + mpp_chain_static_lds_bytes(c->lanes > 0 ? 4 : c->spec);
+}
 
 // The reference's point set has no capacity (Python sets, point_set.py:45-188); a chain here lives in one workgroup's
 // LDS with `point_capacity` slots and `cell_capacity` entries per cell of the spatial hash.  A step that would exceed
@@ -762,7 +768,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   const int occ = (grid >= 1024) ? 2 : 1;
   for (;;) {
     size_t lds = chain_lds(c, c->cap, c->cell_cap);
-    if (lds > MPP_LDS_LIMIT)
+    if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
                   lds, MPP_LDS_LIMIT);
     c->hp.cap = c->cap; c->hp.cell_cap = c->cell_cap;
@@ -789,7 +795,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     if (cell) new_cell = c->cell_cap * 2 > 64 ? 64 : c->cell_cap * 2;
     if (point) new_cap = c->cap * 2 > 65535 ? 65535 : c->cap * 2;
     if (!can_grow || (cell && new_cell == c->cell_cap) || (point && new_cap == c->cap) ||
-        chain_lds(c, new_cap, new_cell) > MPP_LDS_LIMIT) {
+        chain_lds_total(c, new_cap, new_cell) > MPP_LDS_LIMIT) {
       for (int t = 0; t < grid; ++t)
         if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
     }

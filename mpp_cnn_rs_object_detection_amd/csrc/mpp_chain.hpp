@@ -28,6 +28,7 @@
 #include "mpp_device.hpp"
 
 #define STASH 32              // neighbour updates remembered per speculative step
+#define MPP_LDS_PARAMS_MIN_WAVES 4   // chains with at least this many waves read the parameter block from an LDS copy
 #define ERR_CELL_OVERFLOW 1
 #define ERR_POINT_OVERFLOW 2
 #define ERR_BAD_TARGET 3

@@ -12,6 +12,20 @@
 // SIMD).  Throughput runs over many one-wave chains ask for OCC = 2 explicitly so that two chains share a SIMD and
 // hide each other's latencies.
 // SM: the instantiation that also knows the split / merge kernels (mpp_split_merge.hpp); the others carry none of it.
+template <bool IN_LDS>
+__device__ __forceinline__ const DevParams *stage_params(const DevParams &Pv, int nthr) {
+  if constexpr (IN_LDS) {
+    __shared__ DevParams s_P;
+    const int *src = (const int *)&Pv;
+    int *dst = (int *)&s_P;
+    for (int i = threadIdx.x; i < (int)(sizeof(DevParams) / 4); i += nthr) dst[i] = src[i];
+    __syncthreads();
+    return &s_P;
+  } else {
+    return &Pv;
+  }
+}
+
 // FAST: the energy model is (pair 0 = rectangle overlap / max, pair 1 = alignment / min) -- both shipped setups; the pair
 // loops of eval_delta are then straight-line code (chosen by the host; the generic instantiations cover everything else).
 template <int WAVES, int LPW, bool DIAG, int OCC, bool SM, bool FAST = false>
@@ -26,7 +40,11 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   // the parameter block travels BY VALUE: it then lives in the kernel-argument segment (constant address space),
   // so every P->field is a scalar load the compiler may cache and hoist, not a vector-memory load in the
   // dependency chain of the step
-  const DevParams *P = &Pv;
+  // Latency-mode chains (4 or more speculative waves: one chain per CU, LDS to spare) read the block from an LDS copy:
+  // ds_reads return in order and overlap with the other LDS traffic, while a scalar load's wait (lgkmcnt(0), scalar loads
+  // return out of order) drains everything in flight -- 562 k against 549 k proposals/s on the bench tile.  Throughput
+  // launches (one or two waves per chain) keep their LDS for occupancy.
+  const DevParams *P = stage_params<(WAVES >= MPP_LDS_PARAMS_MIN_WAVES)>(Pv, WAVE * WAVES);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = tile0 + blockIdx.x;
   Chain c;
@@ -573,6 +591,10 @@ extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int t
 // ---- host-side launcher ----------------------------------------------------------------------------
 extern "C" size_t mpp_chain_lds_bytes(int cap, int ncell, int cell_cap, int spec, int rowbase_n, int waves) {
   return lds_bytes(cap, ncell, cell_cap, spec, rowbase_n, waves);
+}
+// static LDS a chain kernel with `waves` waves uses besides its dynamic allocation (the staged parameter block)
+extern "C" size_t mpp_chain_static_lds_bytes(int waves) {
+  return waves >= MPP_LDS_PARAMS_MIN_WAVES ? ((sizeof(DevParams) + 15) & ~(size_t)15) : 0;
 }
 
 template <int WAVES, int LPW, bool DIAG, int OCC, bool SM, bool FAST = false>
