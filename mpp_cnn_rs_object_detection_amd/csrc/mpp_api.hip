@@ -789,8 +789,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
       else if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
     }
     if (!cell && !point) return 0;
-    // split / merge steps change two points on the live state: they are not restartable, the limits stay hard there
-    const bool can_grow = c->auto_grow && c->hp.n_kernels <= MPP_K_SPLIT;
+    const bool can_grow = c->auto_grow != 0;
     int new_cell = c->cell_cap, new_cap = c->cap;
     if (cell) new_cell = c->cell_cap * 2 > 64 ? 64 : c->cell_cap * 2;
     if (point) new_cap = c->cap * 2 > 65535 ? 65535 : c->cap * 2;

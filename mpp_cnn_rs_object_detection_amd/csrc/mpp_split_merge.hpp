@@ -244,6 +244,15 @@ __device__ inline void sm_step(const Chain &c, Rec &r, int ri, int n, double T, 
     if (n >= P->cap) { *err = ERR_POINT_OVERFLOW; r.accepted = 0; return; }
     Rect a0, a1;
     sm_split_rects(P, p0, r.aux0, r.aux1, r.as, r.ar, r.aa, &a0, &a1);
+    {                         // room in the two target cells?  checked before anything changes, so that a chain that
+      int ci, cj;             // stops here can be continued with a larger cell capacity (mpp_api.hip: run_chain)
+      const int cp = cell_index(c, p0.x, p0.y, &ci, &cj), c0 = cell_index(c, a0.x, a0.y, &ci, &cj),
+                c1 = cell_index(c, a1.x, a1.y, &ci, &cj);
+      const int need0 = c0 != cp ? 1 : 0, need1 = 1 + (c1 == c0 ? need0 : 0);
+      if ((int)L.cell_cnt[c0] + need0 > c.h.cell_cap || (int)L.cell_cnt[c1] + need1 > c.h.cell_cap) {
+        *err = ERR_CELL_OVERFLOW; r.accepted = 0; return;
+      }
+    }
     const int nn0 = sm_count_potential(c, a0.x, a0.y) + 1, nn1 = sm_count_potential(c, a1.x, a1.y) + 1;
     const double nb = (double)(n + 1);
     fwd = pk[MPP_K_SPLIT] * ((1.0 / (double)n) * sm_split_pdf(P, r.as, r.ar, r.aa)) / intensity;
@@ -267,6 +276,11 @@ __device__ inline void sm_step(const Chain &c, Rec &r, int ri, int n, double T, 
     if (n_nb < 1) n_nb = 1;                           // (a replayed pair further apart than the radius)
     Rect q;
     sm_merge_rect(P, p0, p1, &q);
+    {
+      int ci, cj;
+      const int cp = cell_index(c, p0.x, p0.y, &ci, &cj), cq = cell_index(c, q.x, q.y, &ci, &cj);
+      if (cq != cp && (int)L.cell_cnt[cq] + 1 > c.h.cell_cap) { *err = ERR_CELL_OVERFLOW; r.accepted = 0; return; }
+    }
     fwd = pk[MPP_K_MERGE] * ((1.0 / (double)n) * (1.0 / (double)n_nb));
     bwd = pk[MPP_K_SPLIT] * ((1.0 / (double)(n - 1)) *
                              sm_split_pdf(P, (p0.s - p1.s) / 2.0, (p0.r - p1.r) / 2.0, (p0.a - p1.a) / 2.0)) / intensity;

@@ -104,7 +104,9 @@ def test_without_auto_grow_the_chain_stops_before_the_step_and_can_be_continued_
 @pytest.mark.parametrize("k", [1, 17, 21, 32, 66, 84, 100])
 def test_hot_soak_cases_complete(k):
     """T0 = 5 cases of the chain soak (profiles/tools/soak.py): 25 of 400 such cases stopped with 'cell overflowed' in
-    round 1 (profiles/r01_soak.txt).  They now run to the end and equal the oracle."""
+    round 1 (profiles/r01_soak.txt).  They now run to the end and equal the oracle.  (Chains with the split / merge
+    kernels grow their cells the same way -- their two-point steps check the room in the target cells before they change
+    anything -- but a hot, crowded one can still stop at the merge kernel's 32-candidate neighbour list.)"""
     c = soak_case(k)
     t = c["tile"]
     o = oracle.Oracle(t.shape, t.det, t.marks, c["model"], c["kd"])
