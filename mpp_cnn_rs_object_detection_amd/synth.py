@@ -209,3 +209,26 @@ def make_mosaic(n_side: int = 4, tile: int = 512, n_objects: int = 200, first_ti
             xy.append(t.gt_xy + np.array([i * tile, j * tile], dtype=np.int32))
             mk.append(t.gt_marks)
     return det, marks, np.concatenate(xy), np.concatenate(mk)
+
+
+# ---- score-map nets without trained weights (there is no model.pt in the build container) ---------------------------
+def random_score_nets(seed: int = 0, device: int = 0, dtype=None):
+    """Seeded random-init PosNet + ShapeNet as a ``ScoreMapNets``.  What such nets 'detect' is meaningless; the path
+    from an image to scored detections -- and its cost -- is what runs."""
+    import torch
+    from . import unet
+    torch.manual_seed(seed)
+    pos, shp = unet.PosNet(), unet.ShapeNet()
+    return unet.ScoreMapNets(pos, shp, device=device, dtype=dtype or torch.float32)
+
+
+def calibrate_div_clf(nets, img_crop, frac: float = 0.0015):
+    """Re-scale the 1x1 "div_clf" of a random posnet so that the detection map fires: the most convergent ``frac`` of the
+    pixels of ``img_crop`` reach det = 0.9 (bias as shipped, pos_net_model.py:338-346)."""
+    import torch
+    nets.div_w, nets.div_b = -1.0, 0.0
+    det0, _ = nets.infer(img_crop)
+    z = torch.logit(det0.flatten().double().clamp(1e-9, 1 - 1e-9))          # = -(divergence * mask)
+    q = float(torch.quantile(z[::7].float(), 1.0 - frac))
+    nets.div_b = -2.128434
+    nets.div_w = -(2.2 - nets.div_b) / max(q, 1e-9)

@@ -155,25 +155,11 @@ def test_config4_2048_mosaic_mpp_log_through_infer_image():
 
 
 def random_nets(seed=0, device=0, dtype=None):
-    """seeded random-init PosNet + ShapeNet (no trained model.pt exists in the container).  The divergence
-    classifier is re-scaled so that the detection map has peaks above the detection threshold; what the nets 'detect' is
-    meaningless, the path from the image to scored detections is what runs."""
-    import torch
-    from mpp_cnn_rs_object_detection_amd import unet
-    torch.manual_seed(seed)
-    pos, shp = unet.PosNet(), unet.ShapeNet()
-    return unet.ScoreMapNets(pos, shp, device=device, dtype=dtype or torch.float32)
+    return synth.random_score_nets(seed, device, dtype)
 
 
 def calibrate_div_clf(nets, img_crop, frac=0.0015):
-    """the 1x1 "div_clf" of a random posnet: the most convergent ``frac`` of the pixels reach det = 0.9"""
-    import torch
-    nets.div_w, nets.div_b = -1.0, 0.0
-    det0, _ = nets.infer(img_crop)
-    z = torch.logit(det0.flatten().double().clamp(1e-9, 1 - 1e-9))          # = -(divergence * mask)
-    q = float(torch.quantile(z[::7].float(), 1.0 - frac))
-    nets.div_b = -2.128434
-    nets.div_w = -(2.2 - nets.div_b) / max(q, 1e-9)
+    return synth.calibrate_div_clf(nets, img_crop, frac)
 
 
 def test_config5_4096_scene_with_the_nets():
