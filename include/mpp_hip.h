@@ -127,7 +127,10 @@ int mpp_synchronize(mpp_ctx *ctx);
  * mpp_run / mpp_replay double the capacity (while the chain still fits the 160 KB of LDS) and continue it -- the reference's
  * point set has no capacity (point_set/point_set.py:45-188); with 0 the call fails with -11 / -12 and the chain can be
  * continued by hand from the written-back state ("grow_events", read-only, counts the re-launches), "replicas" (before mpp_set_maps): v independent chains per tile, chain t on the maps of
- * tile t % n_tiles; "force_accept": apply every proposal without the Metropolis test (the kernel random
+ * tile t % n_tiles; "remap_table" (-1 auto, default; 0 never; 1 always): chains of a model with the
+ * MPP_U_SHAPE_REMAP term read the remapped mark probabilities from [H][W][32] float64 tables built once per mpp_set_maps (as
+ * the reference does, energy_setup_legacy.py:142-147) instead of evaluating three sigmoids per proposal -- the same values bit
+ * for bit; auto: while the tables fit 16 GB; reading it back tells whether they are in use; "force_accept": apply every proposal without the Metropolis test (the kernel random
  * walks of models/mpp/perturbation_sampler.py:152-169); "scratch_grid_min_points" (default 256; 0 = never): configurations of
  * at least that many points get a candidate grid (PointsSet.get_potential_neighbors, point_set.py:111-145) for
  * mpp_total_energy / mpp_delta_batch / mpp_delta_vectors / mpp_papangelou instead of a scan of all points.  Read-only: "n_chains", "lds_bytes", and the spatial-hash

@@ -15,6 +15,7 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
                                        const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
                                        long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
+extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
                                          int n_cases, const int32_t *rem_off, const int32_t *rem,
@@ -72,6 +73,10 @@ struct mpp_ctx {
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
   int64_t *step = nullptr;
   long long *until = nullptr;        // per tile: the absolute step the current mpp_run / mpp_replay call runs it to
+  double *remap[3] = {nullptr, nullptr, nullptr};   // tables of the remapped marks (chains only), see ensure_remap_tables
+  bool remap_dirty = true;
+  int remap_mode = -1;               // option "remap_table": -1 auto (when the tables fit remap_budget), 0 never, 1 always
+  size_t remap_budget = (size_t)16 << 30;
   int auto_grow = 1, grow_events = 0; // capacity overflow -> raise the capacity and continue (see run_chain)
   std::vector<double> intensity;
   std::vector<TileRef> h_tiles;
@@ -169,6 +174,8 @@ static void free_tiles(mpp_ctx *c) {
     for (int k = 0; k < 3; ++k) if (c->m[k]) (void)hipFree(c->m[k]);
   }
   c->det = nullptr; c->m[0] = c->m[1] = c->m[2] = nullptr;
+  for (int k = 0; k < 3; ++k) if (c->remap[k]) { (void)hipFree(c->remap[k]); c->remap[k] = nullptr; }
+  c->remap_dirty = true;
   if (c->boxsum) { (void)hipFree(c->boxsum); c->boxsum = nullptr; }
   void *ptrs[] = {c->rowpart, c->rowbase, c->rowtot, c->px, c->py, c->n, c->errd, c->ps, c->pr, c->pa, c->T, c->step,
                   c->d_tiles, c->until};
@@ -234,6 +241,9 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     c->cell_cap = (int)v; c->params_dirty = true;
   } else if (!strcmp(name, "auto_grow")) {
     c->auto_grow = v ? 1 : 0;
+  } else if (!strcmp(name, "remap_table")) {
+    if (v < -1 || v > 1) return fail(c, -1, "remap_table must be -1 (auto), 0 or 1");
+    c->remap_mode = (int)v; c->remap_dirty = true;
   } else if (!strcmp(name, "force_accept")) {
     c->hp.force_accept = v ? 1 : 0; c->params_dirty = true;
   } else return fail(c, -1, "unknown option %s", name);
@@ -248,6 +258,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "auto_grow")) return c->auto_grow;
+  if (!strcmp(name, "remap_table")) return c->remap[0] ? 1 : 0;       // are the tables in use right now?
   if (!strcmp(name, "grow_events")) return c->grow_events;
   if (!strcmp(name, "scratch_grid_min_points")) return c->grid_min_points;
   if (!strcmp(name, "force_accept")) return c->hp.force_accept;
@@ -316,6 +327,7 @@ extern "C" int mpp_set_model(mpp_ctx *c, const mpp_model *model, const mpp_mappi
   c->hp.model = *model;
   c->hp.maps = *maps;
   c->have_model = true;
+  c->remap_dirty = true;
   refresh_grid(c);
   return 0;
 }
@@ -407,6 +419,8 @@ static int push_state(mpp_ctx *c) {
       r.rowpart = (const MPP_GLOBAL double *)(c->rowpart + m * hw);
       r.rowbase = (const MPP_GLOBAL double *)(c->rowbase + m * (c->H + 1));
       r.boxsum = (const MPP_GLOBAL double *)(c->boxsum + m * hw);
+      for (int k = 0; k < 3; ++k)
+        r.rm[k] = c->remap[k] ? (const MPP_GLOBAL double *)(c->remap[k] + m * hw * MPP_NCLASS) : nullptr;
       r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
@@ -744,10 +758,54 @@ static size_t chain_lds_total(mpp_ctx *c, int cap, int cell_cap) {
 // with auto_grow (default) the capacity is doubled -- as long as the chain still fits the 160 KB of LDS -- and the same
 // launch is issued again: finished tiles return at once, the stopped ones continue with the very next step, so the
 // chain is the one an unlimited capacity would have produced.
+// A chain evaluates MPP_U_SHAPE_REMAP -- three sigmoids of mark probabilities -- for every proposal that adds a rectangle
+// (~10 % of its vector instructions).  The reference builds the remapped maps once per tile
+// (energy_setup_legacy.py:142-147); so do chains here: [H][W][32] float64 per mark, holding exactly the summands the
+// inline code forms (same expression, same device exp: the chain is byte-identical with and without the tables).  Only
+// for models whose sole use of the mark maps is that term, only for contexts that run chains (the from-scratch energies of
+// EPointsSet evaluate a few thousand points: inline), and only while 3 x 8 B x 32 per pixel fits the budget (16 GB).
+static int ensure_remap_tables(mpp_ctx *c) {
+  if (!c->remap_dirty) return 0;
+  c->remap_dirty = false;
+  const mpp_model &M = c->hp.model;
+  int term = -1;
+  bool other_mark_use = false;
+  for (int k = 0; k < M.n_unit; ++k) {
+    if (M.unit[k].kind == MPP_U_SHAPE_REMAP) term = term < 0 ? k : -2;
+    if (M.unit[k].kind == MPP_U_MARK_NEG || M.unit[k].kind == MPP_U_MARK_REMAP) other_mark_use = true;
+  }
+  const size_t n = (size_t)c->n_maps * c->H * c->W * MPP_NCLASS, bytes = 3 * n * sizeof(double);
+  const bool want = c->remap_mode != 0 && term >= 0 && !other_mark_use && (c->remap_mode == 1 || bytes <= c->remap_budget);
+  bool have = c->remap[0] != nullptr;
+  if (!want) {
+    if (have) {
+      for (int k = 0; k < 3; ++k) { (void)hipFree(c->remap[k]); c->remap[k] = nullptr; }
+      c->tiles_dirty = true;
+    }
+    return 0;
+  }
+  for (int k = 0; k < 3; ++k) {
+    if (!c->remap[k] && hipMalloc((void **)&c->remap[k], n * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();                          // no room: chains evaluate the sigmoids inline (same values)
+      for (int j = 0; j < 3; ++j) if (c->remap[j]) { (void)hipFree(c->remap[j]); c->remap[j] = nullptr; }
+      c->tiles_dirty = true;
+      return 0;
+    }
+    mpp_launch_remap_table(c->stream, c->m[k], n, M.unit[term].p[k], M.unit[term].p[3 + k], c->remap[k]);
+  }
+  HIPCHK(c, hipGetLastError());
+  c->tiles_dirty = true;
+  return 0;
+}
+
 static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t seed, uint32_t chain0,
                      const mpp_proposal *d_tape, int trace_tile, mpp_step_out *d_out, mpp_proposal *d_props) {
   if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
-  int rc = push_state(c);
+  if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
+  if (!c->have_model) return fail(c, -1, "mpp_set_model has not been called");
+  int rc = ensure_remap_tables(c);
+  if (rc) return rc;
+  rc = push_state(c);
   if (rc) return rc;
   // the row level of the birth CDF goes to LDS when it fits and the chain speculates (it shortens the slowest
   // wave of a round); throughput launches of one-wave chains keep their LDS for occupancy

@@ -55,6 +55,7 @@ struct Rec {                  // one speculative step, fully evaluated
   int kernel, tidx, tslot, has_rem, has_add, valid;
   int ax, ay, rx, ry, pid, ncls;
   int accepted, n_stash, gate_a, _pad;
+  int acls, _pad2;            // class of the proposed angle when it is a class edge (KEEP_EDGE_ANGLE), else unused
   double as, ar, aa, aux0, aux1, u_acc, qf, qb, dE;
   double hl, hw, ca, sa, rad, lin_a, ra0, ra1;   // derived data of the proposed point
   double fwd, bwd, log_alpha;                    // filled only when the tile is traced
@@ -63,6 +64,8 @@ struct Rec {                  // one speculative step, fully evaluated
 struct Lds {
   double *s, *r, *a, *ca, *sa, *hl, *hw, *rad, *lin, *red0, *red1;
   double *edges;              // [3][32] copy of the mark bin edges
+  double *trig;               // [2][32] cos / sin of (angle-class edge + pi/2): the corner trigonometry of a rectangle whose
+                              // angle was drawn from the class distribution (data-driven birth / transform) without a sincos
   double *rowbase;            // [H+1] copy of the birth CDF's row level (H <= 1024), else nullptr
   double *stash_v0, *stash_v1;
   double *clip;               // [waves][CLIP_SLOTS][32] polygon buffers of the rectangle clipper
@@ -81,6 +84,7 @@ __host__ __device__ inline size_t lds_bytes(int cap, int ncell, int cell_cap, in
   b += (size_t)11 * cap * sizeof(double);
   b += (size_t)rowbase_n * sizeof(double);
   b += (size_t)3 * MPP_NCLASS * sizeof(double);
+  b += (size_t)2 * MPP_NCLASS * sizeof(double);               // trig
   b += (size_t)2 * spec * STASH * sizeof(double);
   b += (size_t)cap * sizeof(int);
   b += (size_t)cap * sizeof(unsigned short);                  // order
@@ -101,6 +105,7 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
   L.hl = d; d += cap; L.hw = d; d += cap; L.rad = d; d += cap; L.lin = d; d += cap; L.red0 = d; d += cap;
   L.red1 = d; d += cap;
   L.edges = d; d += 3 * MPP_NCLASS;
+  L.trig = d; d += 2 * MPP_NCLASS;
   L.rowbase = rowbase_n > 0 ? d : nullptr; d += rowbase_n;
   L.stash_v0 = d; d += (size_t)spec * STASH; L.stash_v1 = d; d += (size_t)spec * STASH;
   L.clip = d; d += (size_t)waves * CLIP_SLOTS * 32;
@@ -807,7 +812,9 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
 // One 32-bin mark row (128 B): every lane reads the whole row (a broadcast read of one cache line) and
 // sums it in index order -- no cross-lane traffic, wave-uniform result, same order as the oracle.
 // Returns P[cls]/sum; with `draw` the class is first drawn: #{j : cumsum_j <= u*sum}.
-__device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool draw, double u, int *drawn) {
+// `cls2` >= 0: *p2 receives P[cls2]/sum of the same row (the backward probability of the data-driven transform).
+__device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool draw, double u, int *drawn, int cls2 = -1,
+                           double *p2 = nullptr) {
   const float4 *row = (const float4 *)mark_row_w(c.h.W, c.t, k, x, y);
   float v[MPP_NCLASS];
 #pragma unroll
@@ -826,6 +833,12 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
   float pc = 0.f;
 #pragma unroll
   for (int i = 0; i < MPP_NCLASS; ++i) pc = (i == cls) ? v[i] : pc;
+  if (cls2 >= 0) {
+    float pc2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) pc2 = (i == cls2) ? v[i] : pc2;
+    *p2 = (double)pc2 / tot;
+  }
   return (double)pc / tot;
 }
 // `coop`: the wave works on ONE proposal (wave mode).  The three mark rows are then handled by lanes 0, 1 and 2 at
@@ -1030,6 +1043,8 @@ __device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex
 #define KEEP_TRIG 1
 #define KEEP_SIZE 2
 #define KEEP_QF 4             // the forward density was computed while drawing (data-driven birth)
+#define KEEP_QFB 8            // forward AND backward probability were computed while drawing (data-driven transform)
+#define KEEP_EDGE_ANGLE 16    // the proposed angle is the lower edge of class r.ncls: its cos / sin are in the LDS table
 
 // draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
 // w: the step's Philox blocks 0 and 1.  The uniform of the accept test comes from words 6, 7 -- except for the
@@ -1041,7 +1056,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
   double uk = u53(w[0], w[1]);
   int k = 0;
   while (k < P->n_kernels - 1 && P->p_cum[k] <= uk) ++k;
-  r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1;
+  r.kernel = k; r.tidx = -1; r.tslot = -1; r.has_rem = 0; r.has_add = 0; r.pid = -1; r.ncls = -1; r.acls = 0; r._pad2 = 0;
   r.aux0 = r.aux1 = 0.0; r.ax = r.ay = 0; r.as = r.ar = r.aa = 0.0; r.rx = r.ry = 0;
   if (k == MPP_K_UBIRTH || k == MPP_K_DBIRTH || k == MPP_K_SPLIT) {
     uint32_t e[4];
@@ -1127,9 +1142,10 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
                 c2 = __builtin_amdgcn_readlane(cls_l, 2);
       d *= readlane_d(pl, 0); d *= readlane_d(pl, 1); d *= readlane_d(pl, 2);
       r.as = c.L.edges[c0]; r.ar = c.L.edges[MPP_NCLASS + c1]; r.aa = c.L.edges[2 * MPP_NCLASS + c2];
+      r.acls = c2;
     }
     r.qf = d * ((double)c.h.H * (double)c.h.W * 32768.0);
-    *keep = KEEP_QF;
+    *keep = KEEP_QF | (LANE ? 0 : KEEP_EDGE_ANGLE);
     return;
   }
   if (n == 0) return;
@@ -1164,11 +1180,16 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     r.pid = pid; r.aux0 = d;
     *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
   } else {
+    // forward and backward probability come from the row the class is drawn from (transform_kernels.py:203-225): both are
+    // taken here, from the one pass over the row, with the sums in the order proposal_densities() forms them
     int pid = (int)mulhi32(w[3], 3u), cls;
-    row_prob(c, pid, q.x, q.y, 0, true, u32d(w[4]), &cls);
+    const int oc = value_to_class_tab(P, c.L.edges + pid * MPP_NCLASS, pid, mark_of(q, pid));
+    double pb = 0.0;
+    r.qf = row_prob(c, pid, q.x, q.y, 0, true, u32d(w[4]), &cls, oc, &pb);
+    r.qb = pb;
     set_mark(q, pid, c.L.edges[pid * MPP_NCLASS + cls]);
-    r.pid = pid; r.ncls = cls;
-    *keep = pid == 2 ? KEEP_SIZE : KEEP_TRIG;
+    r.pid = pid; r.ncls = cls; r.acls = cls;
+    *keep = (pid == 2 ? KEEP_SIZE : KEEP_TRIG) | KEEP_QFB | (pid == 2 ? KEEP_EDGE_ANGLE : 0);
   }
   // (materialised here through an empty asm: in the traced instantiation the compiler otherwise lost the row of the
   // data-driven transform branch -- r.ax came out as 0 -- when the kernel grew; ROCm 7.2 hipcc)
@@ -1182,6 +1203,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
 __device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep, bool coop) {
   const DevParams *P = c.P;
   if (keep & KEEP_QF) { r.qb = 1.0; return; }
+  if (keep & KEEP_QFB) return;
   r.qf = 1.0; r.qb = 1.0;
   Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
   switch (r.kernel) {
@@ -1285,7 +1307,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
   const DevParams *P = c.P;
   const Lds &L = c.L;
   // the score-map values of the proposed rectangle: requested first, used after the densities and the trigonometry
-  MapVals mv{0.f, 0.f, 0.f, 0.f};
+  MapVals mv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
 #ifndef MPP_NO_HOIST
   if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
 #endif
@@ -1305,6 +1327,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
         ag.rad = geo_radius(ag.g);
       }
       if (keep & KEEP_TRIG) { ag.g.ca = L.ca[r.tslot]; ag.g.sa = L.sa[r.tslot]; }
+      else if (keep & KEEP_EDGE_ANGLE) { ag.g.ca = L.trig[r.acls]; ag.g.sa = L.trig[MPP_NCLASS + r.acls]; }
       else { double al = add.a + MPP_PI / 2.0; ag.g.ca = cos(al); ag.g.sa = sin(al); }
       EPROF(5);
 #ifdef MPP_NO_HOIST

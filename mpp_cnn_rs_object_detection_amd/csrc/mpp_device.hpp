@@ -55,6 +55,9 @@ struct TileRef {
   const MPP_GLOBAL double *rowpart;   // [H][W] inclusive partial sums of det within each row
   const MPP_GLOBAL double *rowbase;   // [H+1] exclusive prefix of row totals; rowbase[H] = sum(det)
   const MPP_GLOBAL double *boxsum;    // [H][W] sum of det over the (2*max_delta+1)^2 window clipped to the tile
+  // optional [H][W][32] tables of the remapped mark probabilities -2*sigmoid(coef_k*P_k+icpt_k)+1 (the reference builds
+  // these maps once per tile, energy_setup_legacy.py:142-147); nullptr: the three sigmoids are evaluated per proposal
+  const MPP_GLOBAL double *rm[3];
   // point configuration, dense slots (capacity cap)
   int32_t *px, *py;
   double *ps, *pr, *pa;
@@ -220,14 +223,21 @@ __device__ __forceinline__ const float *mark_row(const DevParams *P, const TileR
 
 // the score-map values a rectangle's unit terms can ask for: det at its pixel and, per mark, the probability of the
 // mark's class there.  Fetched together (four independent loads, one memory latency) before the terms are evaluated.
-struct MapVals { float det, m0, m1, m2; };
+struct MapVals { float det, m0, m1, m2; double r0, r1, r2; int tab; };
 // (W: the tile width, passed separately so that the chain can hand over its register copy instead of a scalar load)
 __device__ __forceinline__ MapVals load_map_vals_w(const DevParams *P, int W, const TileRef &t, const double *edges, const Rect &q) {
   const size_t px = (size_t)q.x * W + q.y, pix = px * MPP_NCLASS;
   const int c0 = value_to_class_tab(P, edges, 0, q.s), c1 = value_to_class_tab(P, edges + MPP_NCLASS, 1, q.r),
             c2 = value_to_class_tab(P, edges + 2 * MPP_NCLASS, 2, q.a);
   MapVals v;
-  v.det = t.det[px]; v.m0 = t.m[0][pix + c0]; v.m1 = t.m[1][pix + c1]; v.m2 = t.m[2][pix + c2];
+  v.det = t.det[px];
+  if (t.rm[0] != nullptr) {        // (the host builds the tables only for models whose sole use of the marks is SHAPE_REMAP)
+    v.r0 = t.rm[0][pix + c0]; v.r1 = t.rm[1][pix + c1]; v.r2 = t.rm[2][pix + c2];
+    v.m0 = v.m1 = v.m2 = 0.f; v.tab = 1;
+  } else {
+    v.m0 = t.m[0][pix + c0]; v.m1 = t.m[1][pix + c1]; v.m2 = t.m[2][pix + c2];
+    v.r0 = v.r1 = v.r2 = 0.0; v.tab = 0;
+  }
   return v;
 }
 __device__ __forceinline__ MapVals load_map_vals(const DevParams *P, const TileRef &t, const double *edges, const Rect &q) {
@@ -246,6 +256,11 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
       return (double)e;
     }
     case MPP_U_SHAPE_REMAP: {
+      if (mv.tab) {                  // table entries hold exactly the three summands formed below
+        double acc = 0.0;
+        acc += mv.r0; acc += mv.r1; acc += mv.r2;
+        return acc / 3.0;
+      }
       // the three sigmoids are independent chains: keep them side by side
       double p0 = (double)mv.m0, p1 = (double)mv.m1, p2 = (double)mv.m2;
 #ifdef MPP_EXP_NOEXP      /* timing experiment only: what would a table of the remapped marks save? (wrong chain) */

@@ -491,3 +491,20 @@ extern "C" int mpp_launch_shapenet_epilogue_nhwc(hipStream_t st, const void *log
   else return -1;
   return 0;
 }
+
+
+// ---- remapped mark tables: out[i] = -2 * sigmoid(coef * P[i] + icpt) + 1 for every (pixel, class) of one mark map, in
+// the arithmetic of unit_value(MPP_U_SHAPE_REMAP) (the reference: apply_remap_param_dist, energy_calibration.py:134-139,
+// once per tile in energy_setup_legacy.py:142-147).  HBM-bound: 4 B read + 8 B written per entry.
+__global__ __launch_bounds__(256) void k_remap_table(const float *__restrict__ m, size_t n, double coef, double icpt,
+                                                     double *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double p = (double)m[i];
+    const double e = exp(-(p * coef + icpt));
+    out[i] = -2.0 * (1.0 / (1.0 + e)) + 1.0;
+  }
+}
+extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out) {
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(k_remap_table, dim3((unsigned)(blocks < 65536 * 16 ? blocks : 65536 * 16)), dim3(256), 0, st, m, n, coef, icpt, out);
+}

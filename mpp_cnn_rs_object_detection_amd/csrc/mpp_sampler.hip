@@ -66,6 +66,10 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   int err = __builtin_amdgcn_readfirstlane(*c.t.err);
   if (n0 > cap) { n0 = cap; err = ERR_POINT_OVERFLOW; }
   for (int i = tid; i < 3 * MPP_NCLASS; i += nthr) L.edges[i] = P->maps.edges[i / MPP_NCLASS][i % MPP_NCLASS];
+  for (int i = tid; i < MPP_NCLASS; i += nthr) {       // the expression of make_geo() / evaluate(): the same bits
+    const double al = P->maps.edges[2][i] + MPP_PI / 2.0;
+    L.trig[i] = cos(al); L.trig[MPP_NCLASS + i] = sin(al);
+  }
   for (int i = tid; i < rowbase_n; i += nthr) L.rowbase[i] = c.t.rowbase[i];
   for (int i = tid; i < cap; i += nthr) L.order[i] = (unsigned short)i;
   for (int i = tid; i < ncell; i += nthr) L.cell_cnt[i] = 0;

@@ -378,3 +378,42 @@ def test_soak_cases_that_once_failed(case):
         gxy, gm = ctx.get_points()
         np.testing.assert_array_equal(gxy, oxy, err_msg=f"{c['text']} spec {spec}")
         np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
+
+
+def test_remap_tables_and_trig_table_do_not_change_the_chain():
+    """Chains of a model with the SHAPE_REMAP term read the remapped mark probabilities from tables built once per
+    `mpp_set_maps` (the reference builds these maps once per tile, energy_setup_legacy.py:142-147) instead of evaluating
+    three sigmoids per proposal; class-edge angles take their corner trigonometry from a 32-entry table.  Same values bit
+    for bit: traced records, proposals and configurations equal the run without tables, and the oracle's."""
+    t, o, ctx = setup_case(128, 40, "legacy", noise=0.2, spec=8)
+    ctx.set_option("remap_table", 0)
+    ctx.set_schedule(1.0, 0.998, 0.0)
+    a_out, a_props = ctx.run(6000, 17, chain0=4, trace_tile=0)
+    assert ctx.get_option("remap_table") == 0
+    a_xy, a_m = ctx.get_points()
+    t2, o2, ctx2 = setup_case(128, 40, "legacy", noise=0.2, spec=8)
+    ctx2.set_option("remap_table", 1)
+    ctx2.set_schedule(1.0, 0.998, 0.0)
+    b_out, b_props = ctx2.run(6000, 17, chain0=4, trace_tile=0)
+    assert ctx2.get_option("remap_table") == 1
+    for f in a_out.dtype.names:
+        np.testing.assert_array_equal(a_out[f], b_out[f], err_msg=f)
+    for f in a_props.dtype.names:
+        np.testing.assert_array_equal(a_props[f], b_props[f], err_msg=f)
+    b_xy, b_m = ctx2.get_points()
+    np.testing.assert_array_equal(a_xy, b_xy)
+    np.testing.assert_array_equal(a_m, b_m)
+    # untraced production kernel with tables == traced without
+    t3, o3, ctx3 = setup_case(128, 40, "legacy", noise=0.2, spec=8)
+    ctx3.set_schedule(1.0, 0.998, 0.0)
+    ctx3.run(6000, 17, chain0=4)
+    assert ctx3.get_option("remap_table") == 1                      # auto: the tables fit
+    c_xy, c_m = ctx3.get_points()
+    np.testing.assert_array_equal(a_xy, c_xy)
+    np.testing.assert_array_equal(a_m, c_m)
+    assert ctx3.total_energy() == ctx.total_energy()                # the from-scratch kernels read the same tables / sigmoids
+    # the no-calibration setup uses the marks directly: no tables
+    t4, o4, ctx4 = setup_case(96, 20, "no-calibration", noise=0.2, spec=8)
+    ctx4.set_schedule(1.0, 0.998, 0.0)
+    ctx4.run(500, 1)
+    assert ctx4.get_option("remap_table") == 0
