@@ -125,6 +125,19 @@ __device__ inline Lds carve(unsigned char *base, int cap, int ncell, int cell_ca
 
 // the pair terms' parameters, read ONCE per launch into registers: inside the non-unrolled loops of eval_delta every
 // P->model.pair[p].field was a scalar load followed by a wait (the chain kernel is built without machine LICM)
+// a wave-uniform value pinned to scalar registers (the parameter block may be an LDS copy, whose reads land in vector
+// registers: 20 VGPRs for the pair terms alone); the empty asm keeps the compiler from re-reading or re-deriving it
+__device__ __forceinline__ int launder_s(int v) {
+  v = __builtin_amdgcn_readfirstlane(v);
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ __forceinline__ double launder_d(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 struct PairRegs { int kind, reduce, maxd2, gated; double coef, p0, max_dist; };
 // The grid facts every step asks for many times.  The parameter block lives in the kernel-argument segment, every
 // P->field in the step loop is a scalar load (the kernel is built without machine LICM), and a scalar load's wait --
@@ -141,11 +154,6 @@ struct Chain {
   PairRegs pr0, pr1;
   HotP h;
 };
-__device__ __forceinline__ int launder_s(int v) {
-  v = __builtin_amdgcn_readfirstlane(v);
-  asm volatile("" : "+s"(v));
-  return v;
-}
 __device__ __forceinline__ void load_hot(Chain &c) {
   const DevParams *Q = c.P;
   c.h.H = launder_s(Q->H); c.h.W = launder_s(Q->W); c.h.nx = launder_s(Q->nx); c.h.ny = launder_s(Q->ny);
@@ -154,12 +162,12 @@ __device__ __forceinline__ void load_hot(Chain &c) {
 __device__ __forceinline__ PairRegs load_pair_regs(const DevParams *P, int p) {
   PairRegs r;
   const mpp_pair_term &t = P->model.pair[p];
-  r.kind = t.kind; r.reduce = t.reduce; r.maxd2 = P->maxd2[p]; r.gated = t.gated;
-  r.coef = t.coef; r.p0 = t.p[0]; r.max_dist = t.max_dist;
+  r.kind = launder_s(t.kind); r.reduce = launder_s(t.reduce); r.maxd2 = launder_s(P->maxd2[p]); r.gated = launder_s(t.gated);
+  r.coef = launder_d(t.coef); r.p0 = launder_d(t.p[0]); r.max_dist = launder_d(t.max_dist);
   return r;
 }
 __device__ __forceinline__ void load_model_regs(Chain &c) {
-  c.np = c.P->model.n_pair; c.comb = c.P->model.combinator;
+  c.np = launder_s(c.P->model.n_pair); c.comb = launder_s(c.P->model.combinator);
   c.pr0 = load_pair_regs(c.P, 0); c.pr1 = load_pair_regs(c.P, 1);
 }
 __device__ __forceinline__ PairRegs pair_regs(const Chain &c, int p) {
