@@ -189,6 +189,12 @@ int mpp_replay(mpp_ctx *ctx, int tile, int n, const mpp_proposal *tape, mpp_step
  * ctr=(step, block, chain = chain0+tile)).  trace_tile>=0 records that tile's steps. */
 int mpp_run(mpp_ctx *ctx, int64_t n_steps, uint64_t seed, uint32_t chain0, int trace_tile,
             mpp_step_out *out_or_null, mpp_proposal *props_or_null);
+/* Per-chain Philox keys: chain t of the ctx draws its proposals from Philox4x32-10(key = seeds[t], ctr = (step, block,
+ * chains[t])) instead of (the launch's seed, chain0 + t).  This is what lets the tiles of SEVERAL images share one launch --
+ * the reference samples image after image (mpp_model.py:220-262), one kernel launch per image would leave most of the GPU
+ * idle -- while every tile runs exactly the chain it would run in a launch of its own image.  n = number of chains of the
+ * ctx; seeds == NULL or chains == NULL: back to mpp_run's arguments.  Reset by mpp_set_maps. */
+int mpp_set_chain_keys(mpp_ctx *ctx, int n, const uint64_t *seeds, const uint32_t *chains);
 int mpp_step_index(mpp_ctx *ctx, int tile, int64_t *step);
 /* time of the last mpp_run / mpp_replay kernel in ms (HIP events on the ctx's stream) */
 int mpp_last_kernel_ms(mpp_ctx *ctx, double *ms);

@@ -79,6 +79,8 @@ struct mpp_ctx {
   size_t remap_budget = (size_t)16 << 30;
   int auto_grow = 1, grow_events = 0; // capacity overflow -> raise the capacity and continue (see run_chain)
   std::vector<double> intensity;
+  std::vector<uint64_t> key_seed;    // per-chain Philox key / chain id (mpp_set_chain_keys); empty: the launch's seed, chain0 + tile
+  std::vector<uint32_t> key_chain;
   std::vector<TileRef> h_tiles;
   TileRef *d_tiles = nullptr;
   double sched[3] = {1.0, 1.0, 0.0};
@@ -140,8 +142,8 @@ static const char *chain_error_text(int e) {
   return "unknown chain error";
 }
 
-// 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections
-extern "C" int mpp_abi_version(void) { return 4; }
+// 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections; 5: mpp_set_chain_keys, options auto_grow / remap_table
+extern "C" int mpp_abi_version(void) { return 5; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -364,6 +366,7 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   HIPCHK(c, hipStreamSynchronize(c->stream));
   free_tiles(c);
   c->n_maps = n_tiles; c->n_tiles = n_tiles * c->replicas; c->H = H; c->W = W;
+  c->key_seed.clear(); c->key_chain.clear();
   const size_t hw = (size_t)H * W, M = (size_t)n_tiles, T = (size_t)c->n_tiles;
   const float *src[4] = {det, m0, m1, m2};
   float **dst[4] = {&c->det, &c->m[0], &c->m[1], &c->m[2]};
@@ -425,6 +428,8 @@ static int push_state(mpp_ctx *c) {
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
       r.intensity = c->intensity[t];
+      const bool own = (int)c->key_seed.size() == c->n_tiles;
+      r.key_on = own ? 1u : 0u; r.key_seed = own ? c->key_seed[t] : 0ull; r.key_chain = own ? c->key_chain[t] : 0u;
     }
     HIPCHK(c, hipMemcpyAsync(c->d_tiles, c->h_tiles.data(), sizeof(TileRef) * c->n_tiles, hipMemcpyHostToDevice,
                              c->stream));
@@ -450,6 +455,18 @@ static int check_tile(mpp_ctx *c, int tile) {
   if (!c) return -1;
   if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
   if (tile < 0 || tile >= c->n_tiles) return fail(c, -1, "tile %d out of range", tile);
+  return 0;
+}
+
+extern "C" int mpp_set_chain_keys(mpp_ctx *c, int n, const uint64_t *seeds, const uint32_t *chains) {
+  if (!c) return -1;
+  if (!seeds || !chains) {                     // back to the launch's seed and chain0 + tile
+    c->key_seed.clear(); c->key_chain.clear(); c->tiles_dirty = true;
+    return 0;
+  }
+  if (!c->have_maps || n != c->n_tiles) return fail(c, -1, "mpp_set_chain_keys: one key per chain of the context (%d)", c->n_tiles);
+  c->key_seed.assign(seeds, seeds + n); c->key_chain.assign(chains, chains + n);
+  c->tiles_dirty = true;
   return 0;
 }
 

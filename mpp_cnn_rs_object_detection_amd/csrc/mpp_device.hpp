@@ -66,6 +66,11 @@ struct TileRef {
   int64_t *step;           // steps done so far
   int32_t *err;            // sticky error code of the chain
   double intensity;
+  // The chain's own Philox key and chain id (mpp_set_chain_keys): tiles of SEVERAL images sampled in one launch keep the
+  // seed of their image and their tile index within it, i.e. the chain they would run in a launch of their own.
+  // key_on == 0: the launch's seed and chain0 + tile.
+  uint64_t key_seed;
+  uint32_t key_chain, key_on;
 };
 
 struct Rect {

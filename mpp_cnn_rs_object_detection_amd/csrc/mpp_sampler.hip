@@ -123,7 +123,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   const long long n_steps = until[tile] - step0;
   // records of a traced tile / tape entries are indexed from the step the host's call started at
   const long long tr0 = step0 - trace_base;
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const unsigned long long seed_t = c.t.key_on ? (unsigned long long)c.t.key_seed : seed;
+  const uint32_t chain_t = c.t.key_on ? c.t.key_chain : chain0 + (uint32_t)tile;
+  const uint32_t k0 = (uint32_t)seed_t, k1 = (uint32_t)(seed_t >> 32);
 #ifdef MPP_PROFILE
   unsigned long long prof_[16] = {0};
 #endif
@@ -190,11 +192,11 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         uint64_t s = (uint64_t)(step0 + my);
 #pragma unroll
         for (uint32_t b = 0; b < 2; ++b)
-          philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain0 + (uint32_t)tile, k0, k1, w + 4 * b);
-        draw_proposal<LANE>(c, w, n, r, &keep, k0, k1, s, chain0 + (uint32_t)tile);
+          philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain_t, k0, k1, w + 4 * b);
+        draw_proposal<LANE>(c, w, n, r, &keep, k0, k1, s, chain_t);
         if (SM && r.kernel >= MPP_K_SPLIT) {
           int e = 0;
-          sm_draw(c, r, ri, n, w, k0, k1, s, chain0 + (uint32_t)tile, &e);
+          sm_draw(c, r, ri, n, w, k0, k1, s, chain_t, &e);
           if (e) { r.valid = 0; r.kernel = -2 - e; }
         } else if (!SM && r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
       }

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
     "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
-    "mpp_replay", "mpp_run", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
+    "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
@@ -119,6 +119,7 @@ def load_library(path: Optional[str] = None):
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
         "mpp_replay": (i32, [vp, i32, i32, vp, vp]),
         "mpp_run": (i32, [vp, i64, C.c_uint64, C.c_uint32, i32, vp, vp]),
+        "mpp_set_chain_keys": (i32, [vp, i32, vp, vp]),
         "mpp_step_index": (i32, [vp, i32, C.POINTER(C.c_int64)]),
         "mpp_last_kernel_ms": (i32, [vp, C.POINTER(dbl)]),
         "mpp_posnet_epilogue": (i32, [vp, i32, i32, i32, i32, vp, dbl, dbl, vp]),
@@ -409,6 +410,17 @@ class MppContext:
             return out, props
         self._check(self._L.mpp_run(self._h, int(n_steps), int(seed), int(chain0), -1, None, None))
         return None
+
+    def set_chain_keys(self, seeds=None, chains=None):
+        """Per-chain Philox key and chain id (``mpp_set_chain_keys``); ``None``: back to ``run``'s seed and chain0 + tile."""
+        if seeds is None or chains is None:
+            self._check(self._L.mpp_set_chain_keys(self._h, 0, None, None))
+            return
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(-1)
+        chains = np.ascontiguousarray(chains, dtype=np.uint32).reshape(-1)
+        if len(seeds) != len(chains):
+            raise ValueError("one seed and one chain id per chain")
+        self._check(self._L.mpp_set_chain_keys(self._h, len(seeds), _ptr(seeds), _ptr(chains)))
 
     def step_index(self, tile: int = 0) -> int:
         s = C.c_int64()

@@ -350,6 +350,52 @@ class MPPModel:
         keep = np.array(keep, dtype=np.int64)
         return [points[k] for k in keep], scores[keep]
 
+    #: tiles sampled per launch when a dataset is inferred on one GPU: tiles of consecutive images are sampled together
+    #: (one workgroup per tile: a launch wants at least the 256 CUs' worth), each with the seed and chain id of its image
+    TILES_PER_LAUNCH = 256
+
+    def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None):
+        """``infer_image`` for several images at once on one GPU: ALL their tiles in ONE launch (the reference samples
+        image after image, `mpp_model.py:220-262`; a DOTA image has 4 - 40 tiles, a launch per image leaves most of the
+        256 CUs idle).  Every tile keeps the seed of its image and its tile index as chain id, so each image's result is
+        exactly what ``infer_image`` returns for it, in the same order of seed draws.  Returns [(detections, scores)]."""
+        regions = regions or [self.region_maps(d) for d in images]
+        p = self.config["inference"]["rjmcmc_params"]
+        alpha, T_target, total, snaps = resolve_schedule(1, p["init_temperature"], p["alpha_t"], p["burn_in"],
+                                                          p["samples_interval"], p["target_temperature"],
+                                                          p.get("iter_multiplier"))
+        layout, tiles, seeds, chains = [], [], [], []
+        for data, region in zip(images, regions):
+            patch, anchors = self.tile_layout(tuple(int(v) for v in data.shape[:2]))
+            seed = int(self.rng.integers(0, 2 ** 63 - 1))
+            mine = []
+            for i, a in enumerate(anchors):
+                t = crop_image_w_maps(region, a, patch)
+                t.crop_data = {"tl_anchor": np.array(a)}
+                mine.append(t)
+            layout.append((len(tiles), len(mine)))
+            tiles += mine
+            seeds += [seed] * len(mine)
+            chains += list(range(len(mine)))
+        if len({tuple(t.shape[:2]) for t in tiles}) > 1:
+            raise ValueError("images whose tiles differ in size cannot share a launch")
+        start = time.perf_counter()
+        sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device, spec_waves=self.spec_waves,
+                                   use_split_merge=bool(p.get("use_split_merge", False)), keys=(seeds, chains))
+        sampler.init("naive")
+        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed=0, chain0=0)
+        logging.info(f"ran {len(tiles)} rjmcmc chains ({len(images)} images) of {total} steps in one launch in "
+                     f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
+        results = []
+        for (first, n), data, region in zip(layout, images, regions):
+            res = [r[-1] if r else [] for r in out[first:first + n]]
+            merged = merge_patches(patches=tiles[first:first + n], results=res, original_image=region, method="distance",
+                                   energy_model=self.energy_model, distance=3, energy_setup=self.energy_setup,
+                                   device=self.device)
+            scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
+            results.append((merged, scores))
+        return results
+
     def _prefetch_images(self, patch_ids, dataset, subset, rank: int = 0, world_size: int = 1):
         """Images with the score maps of this rank's region, one image ahead of the consumer: while the chain kernel of
         image i runs, a worker thread reads image i+1 and (with ``nets``) runs the two U-Nets and their epilogues on a
@@ -396,9 +442,34 @@ class MPPModel:
                 print(f"{patch_id:04}_results.pkl exists, skipping")
                 continue
             todo.append((patch_id, out_file))
-        for (patch_id, out_file), (image_data, region_data) in zip(
-                todo, self._prefetch_images([t[0] for t in todo], dataset, subset, rank, world)):
-            merged, scores = self.infer_image(image_data, rank, world, region_data=region_data)
+        def inferred():
+            """(todo entry, image, detections, scores) in dataset order.  One GPU: the tiles of consecutive images share a
+            launch (``infer_images``); several ranks: image by image, each image's tiles dealt to the ranks."""
+            stream = zip(todo, self._prefetch_images([t[0] for t in todo], dataset, subset, rank, world))
+            if world > 1:
+                for entry, (image_data, region_data) in stream:
+                    merged, scores = self.infer_image(image_data, rank, world, region_data=region_data)
+                    yield entry, image_data, merged, scores
+                return
+            limit = int(self.config["inference"].get("tiles_per_launch", self.TILES_PER_LAUNCH))
+            batch, n_tiles, patch0 = [], 0, None
+
+            def flush():
+                res = self.infer_images([b[1] for b in batch], [b[2] for b in batch])
+                for (entry, image_data, _), (merged, scores) in zip(batch, res):
+                    yield entry, image_data, merged, scores
+
+            for entry, (image_data, region_data) in stream:
+                patch, anchors = self.tile_layout(tuple(int(v) for v in image_data.shape[:2]))
+                if batch and (patch != patch0 or n_tiles + len(anchors) > limit):
+                    yield from flush()
+                    batch, n_tiles = [], 0
+                batch.append((entry, image_data, region_data))
+                n_tiles, patch0 = n_tiles + len(anchors), patch
+            if batch:
+                yield from flush()
+
+        for (patch_id, out_file), image_data, merged, scores in inferred():
             if rank != 0:
                 continue
             pts = list(merged)

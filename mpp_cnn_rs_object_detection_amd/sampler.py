@@ -82,7 +82,10 @@ class TileBatchSampler:
 
     def __init__(self, tiles: Sequence[ImageWMaps], energy_setup, energy_combinator, device: int = 0,
                  point_capacity: int = 1024, spec_waves: Optional[int] = 8, ctx: Optional[MppContext] = None,
-                 use_split_merge: bool = False):
+                 use_split_merge: bool = False, keys=None):
+        """``keys`` = (seeds, chain ids), one per tile: the Philox key and chain id each tile's chain uses instead of the
+        launch's seed and ``chain0 + tile`` -- tiles of several images in one launch keep the chains they would run in a
+        launch of their own image (``mpp_set_chain_keys``)."""
         self.use_split_merge = use_split_merge
         shapes = {tuple(t.shape[:2]) for t in tiles}
         if len(shapes) != 1:
@@ -104,6 +107,8 @@ class TileBatchSampler:
             det = np.stack([np.asarray(t.detection_map, dtype=np.float32) for t in tiles])
             marks = [np.stack([np.asarray(t.param_dist_maps[k], dtype=np.float32) for t in tiles]) for k in range(3)]
         self.ctx.set_maps(det, marks)
+        if keys is not None:
+            self.ctx.set_chain_keys(keys[0], keys[1])
         self.ctx.set_model(self.model, self.mappings)
         if auto_spec and ctx is None:
             self.ctx.set_option("spec_waves", choose_spec_waves(self.ctx, len(self.tiles), use_split_merge))

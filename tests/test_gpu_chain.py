@@ -417,3 +417,37 @@ def test_remap_tables_and_trig_table_do_not_change_the_chain():
     ctx4.set_schedule(1.0, 0.998, 0.0)
     ctx4.run(500, 1)
     assert ctx4.get_option("remap_table") == 0
+
+
+def test_chain_keys_let_tiles_of_different_images_share_a_launch():
+    """`mpp_set_chain_keys`: every chain of a launch with its own Philox key and chain id equals the chain it runs in a
+    launch of its own (seed, chain0) -- what `MPPModel.infer_images` relies on."""
+    tiles = [synth.make_tile(96, 14, tile_id=60 + i, noise=0.1) for i in range(3)]
+    setup, comb, model = model_for("legacy")
+    maps = mappings.default_mappings()
+    kd = kernels.make_kernels(maps, 14.0)
+    seeds, chains = [11, 2 ** 40 + 5, 11], [0, 3, 1]
+    alone = []
+    for t, s, ch in zip(tiles, seeds, chains):
+        ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=8)
+        ctx.set_maps(t.det, t.marks); ctx.set_model(model, maps); ctx.naive_init(setup.detection_threshold, 6.0)
+        ctx.set_kernels(kd); ctx.set_schedule(1.0, 0.998, 0.0)
+        ctx.run(4000, seed=s, chain0=ch)
+        alone.append(ctx.get_points(0))
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=8)
+    ctx.set_maps(np.stack([t.det for t in tiles]), [np.stack([t.marks[k] for t in tiles]) for k in range(3)])
+    ctx.set_chain_keys(seeds, chains)
+    ctx.set_model(model, maps); ctx.naive_init(setup.detection_threshold, 6.0)
+    ctx.set_kernels(kd, intensity=np.full(3, 14.0)); ctx.set_schedule(1.0, 0.998, 0.0)
+    ctx.run(4000, seed=999, chain0=77)                      # the launch's own seed / chain0 are not used
+    for i in range(3):
+        xy, m = ctx.get_points(i)
+        np.testing.assert_array_equal(xy, alone[i][0])
+        np.testing.assert_array_equal(m, alone[i][1])
+    ctx.set_chain_keys(None, None)                           # back to (seed, chain0 + tile)
+    ctx.naive_init(setup.detection_threshold, 6.0); ctx.set_schedule(1.0, 0.998, 0.0)
+    ctx.run(4000, seed=11, chain0=0)
+    xy, m = ctx.get_points(0)
+    np.testing.assert_array_equal(xy, alone[0][0])
+    with pytest.raises(hip_api.MppError):
+        ctx.set_chain_keys([1, 2], [0, 1])                   # one key per chain

@@ -379,3 +379,36 @@ def test_main_infer_with_the_unets_on_the_gpu(synthetic_dataset):
             res = pickle.load(f)
         assert len(res["detection_score"]) == len(res["detection_center"]) == len(res["detection_params"])
     assert len(open(out / "dota" / "imageSet.txt").read().split()) == 3
+
+
+def test_dataset_inference_batches_tiles_of_several_images_without_changing_any_result(synthetic_dataset):
+    """``MPPModel.infer`` on one GPU samples the tiles of consecutive images in ONE launch (``infer_images``); every tile
+    keeps the seed of its image and its chain id, so each image's detections and scores are what image-by-image
+    launches give."""
+    root, _ = synthetic_dataset
+    for k, seed in ((8, 23), (9, 24)):
+        write_image(root, "val", k, seed)
+    outs = {}
+    for name, limit in (("batched", 256), ("single", 1)):
+        cfg = json.load(open(root / "model_configs" / "mpp" / "mpp_hrcM.json"))
+        cfg["inference"]["rjmcmc_params"]["burn_in"] = 6000
+        cfg["inference"]["tiles_per_launch"] = limit
+        with open(root / f"cfg_{name}.json", "w") as f:
+            json.dump(cfg, f)
+        env = dict(os.environ, PYTHONPATH=REPO)
+        r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", "infer", "-m", "mpp", "-c", str(root / f"cfg_{name}.json"),
+                            "-d", "SYNTH", "-o"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        launches = [ln for ln in r.stderr.splitlines() if "rjmcmc chains" in ln]
+        assert len(launches) == (1 if name == "batched" else 3), launches            # 3 images x 4 tiles: one launch or three
+        res = {}
+        for k in (7, 8, 9):
+            with open(root / "data" / "inference" / "SYNTH" / "val" / "mpp_hrcM" / f"{k:04}_results.pkl", "rb") as f:
+                res[k] = pickle.load(f)
+        outs[name] = res
+    for k in (7, 8, 9):
+        a, b = outs["batched"][k], outs["single"][k]
+        assert len(a["detection_score"]) > 20
+        np.testing.assert_array_equal(np.asarray(a["detection_center"]), np.asarray(b["detection_center"]))
+        np.testing.assert_array_equal(np.asarray(a["detection_points"]), np.asarray(b["detection_points"]))
+        np.testing.assert_array_equal(np.asarray(a["detection_score"]), np.asarray(b["detection_score"]))
