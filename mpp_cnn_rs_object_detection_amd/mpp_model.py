@@ -240,7 +240,7 @@ class MPPModel:
         if region is None:
             return None
         if image_data.detection_map is not None:
-            return crop_region(image_data, region)
+            return self._resident(crop_region(image_data, region))
         if self.nets is None:
             raise ValueError("the image carries no score maps and no nets were given")
         det, marks = self.nets.infer_region(image_data.image, region)
@@ -248,6 +248,19 @@ class MPPModel:
         return ImageWMaps(image=None, name=image_data.name, shape=(x1 - x0, y1 - y0), detection_map=det,
                           param_dist_maps=marks, mappings=image_data.mappings, param_names=image_data.param_names,
                           gt_config=[], crop_data={"tl_anchor": np.array([x0, y0]), "full_shape": tuple(image_data.shape[:2])})
+
+    def _resident(self, region: ImageWMaps) -> ImageWMaps:
+        """Host score maps (the pickle hand-off) go to the GPU ONCE per image: the tiles are then device views that the
+        sampler stacks on the device, and merge / scoring borrow the same tensors -- instead of one upload of every tile
+        plus one of the whole image for the merge (2 x 100 B per pixel over PCIe)."""
+        if hasattr(region.detection_map, "data_ptr"):
+            return region
+        import torch
+        dev = torch.device("cuda", self.device)
+        region.detection_map = torch.from_numpy(np.ascontiguousarray(region.detection_map, dtype=np.float32)).to(dev)
+        region.param_dist_maps = [torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(dev)
+                                  for m in region.param_dist_maps]
+        return region
 
     def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1, region_data: ImageWMaps = None):
         """Tile, sample, merge and score one image.  Returns (detections, scores): an ``EPointsSet`` for one rank,
