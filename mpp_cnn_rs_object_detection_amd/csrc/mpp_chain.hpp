@@ -1093,6 +1093,12 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
 #endif
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
+#ifdef MPP_PROFILE
+    unsigned long long db_t_ = clock64();
+#define DBPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0 && c.lane == 0) atomicAdd(&g_prof2[i], n_ - db_t_); db_t_ = n_; } while (0)
+#else
+#define DBPROF(i)
+#endif
     const double u = u53(w[3], w[4]), tot = c.L.rowbase ? c.L.rowbase[c.h.H] : c.t.rowbase[c.h.H];
     const double thr = u * tot;                       // cdf <= u <=> partial sum <= u*total
     int row = 0, col = 0;                             // #rows / #columns whose inclusive cdf is <= u (monotone)
@@ -1118,7 +1124,21 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
         if (row >= c.h.H) row = c.h.H - 1;
         base = rb[row];
       };
-      if (c.L.rowbase) row_search(c.L.rowbase); else row_search(c.t.rowbase);
+      // the row level in LDS is searched in two steps of one read and one ballot each: lane k looks at the last row of
+      // block k (S rows per block, 64 blocks), then the lanes of the block found look at its rows -- the count of a
+      // monotone table is the same either way (8 reads and 8 ballots per lane before: 1 300 of the 7 000 cycles of this
+      // draw, which is the slowest wave's kernel in 40 % of the rounds)
+      if (c.L.rowbase && c.h.H <= WAVE * WAVE) {
+        const double *rb = c.L.rowbase;
+        const int S = (c.h.H + WAVE - 1) / WAVE;                       // rows per block
+        const int last = (c.lane + 1) * S;                             // rb[last] = cdf after the block's last row
+        const int blk = __popcll(__ballot(last <= c.h.H && rb[last] <= thr));      // whole blocks at or below the threshold
+        const int i = blk * S + c.lane;
+        row = blk * S + __popcll(__ballot(c.lane < S && i < c.h.H && rb[i + 1] <= thr));
+        if (row >= c.h.H) row = c.h.H - 1;
+        base = rb[row];
+      } else if (c.L.rowbase) row_search(c.L.rowbase); else row_search(c.t.rowbase);
+      DBPROF(13);
       const MPP_GLOBAL double *part = c.t.rowpart + (size_t)row * c.h.W;
       for (int j0 = 0; j0 < c.h.W; j0 += 8 * WAVE) {
         double v[8];
@@ -1129,6 +1149,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
       }
     }
     if (col >= c.h.W) col = c.h.W - 1;
+    DBPROF(14);
     r.ax = row; r.ay = col;
     // marks, and on the way the birth density of the drawn point (shape_samplers.py:103-108; same operation
     // order as birth_density())
@@ -1154,6 +1175,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     }
     r.qf = d * ((double)c.h.H * (double)c.h.W * 32768.0);
     *keep = KEEP_QF | (LANE ? 0 : KEEP_EDGE_ANGLE);
+    DBPROF(15);
     return;
   }
   if (n == 0) return;

@@ -18,6 +18,7 @@ for spec, lanes in ((1, 0), (8, 0)):
     v = np.array(list(buf), dtype=float); names = ['draw','evaluate','commit','sync','dens','geom','unit','evalD','green','barrier_wait']
     buf2 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof2(buf2, 1)
     print('   evalD parts (setup, after-pass, cand-loads, overlap-phase, combine, pair-loop, finish+stash):', [round(x/100001) for x in list(buf2)[:7]], 'clips/step', buf2[8]/100001, 'cands/eval', buf2[9]/max(1,buf2[11]), 'rescans/step', buf2[10]/100001, 'evals/step', buf2[11]/100001, 'zero-area clips/step', buf2[12]/100001)
+    print('   data-driven birth draw (row search, column search, det + mark rows + marks), cycles per birth:', [round(list(buf2)[i] / max(1, 100001 / 9 / (8 if spec == 8 else 1))) for i in (13, 14, 15)])
     buf3 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof3(buf3)
     buf4 = (ctypes.c_ulonglong * 16)(); L.mpp_debug_read_prof4(buf4)
     print('   draw cycles by kernel (UB,UD,DB,DD,GT,DT,GTF,DTF):', [round(buf4[k]/max(1,buf3[8+k])) for k in range(8)])
