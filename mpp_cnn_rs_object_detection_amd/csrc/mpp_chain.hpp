@@ -828,15 +828,33 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
 #pragma unroll
   for (int i = 0; i < 8; ++i) { float4 q = row[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
   double tot = 0.0;
-#pragma unroll
-  for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)v[i];
+#ifdef MPP_NO_CUMSUM
   if (draw) {
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)v[i];
     double acc = 0.0, thr = u * tot;
     int d = 0;
 #pragma unroll
     for (int i = 0; i < MPP_NCLASS; ++i) { acc += (double)v[i]; d += (acc <= thr) ? 1 : 0; }
     cls = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
     *drawn = cls;
+  } else
+#endif
+  if (draw) {
+    // the running sums ARE the partial sums of the total (same order, same roundings): one dependent chain of 32
+    // additions instead of two, the counts afterwards are independent compares
+    double cs[MPP_NCLASS];
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) { tot += (double)v[i]; cs[i] = tot; }
+    const double thr = u * tot;
+    int d = 0;
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) d += (cs[i] <= thr) ? 1 : 0;
+    cls = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
+    *drawn = cls;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)v[i];
   }
   float pc = 0.f;
 #pragma unroll
@@ -1053,13 +1071,40 @@ __device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex
 #define KEEP_QF 4             // the forward density was computed while drawing (data-driven birth)
 #define KEEP_QFB 8            // forward AND backward probability were computed while drawing (data-driven transform)
 #define KEEP_EDGE_ANGLE 16    // the proposed angle is the lower edge of class r.ncls: its cos / sin are in the LDS table
+#define KEEP_MV 32            // the score-map values of the proposed rectangle were fetched while drawing
+
+// Wave mode with remap tables: the kernels that draw a mark class from a score-map row (data-driven birth and
+// transform) know the PIXEL of the proposed rectangle one memory latency before they know its classes.  The three
+// table rows of that pixel (32 float64 each) are requested right then, one entry per lane -- tables 0 and 1 in the two
+// halves of the wave, table 2 in a second load -- next to the mark rows, and the entries of the drawn classes are
+// picked with readlane afterwards: the unit terms no longer wait for a table lookup that depends on the draw.
+struct TabRows { double a, b; };
+__device__ __forceinline__ TabRows tab_rows_request(const Chain &c, size_t pix) {
+  const MPP_GLOBAL double *t0 = c.t.rm[0], *t1 = c.t.rm[1], *t2 = c.t.rm[2];
+  const int e = c.lane & (MPP_NCLASS - 1);
+  TabRows t;
+  t.a = (c.lane < MPP_NCLASS ? t0 : t1)[pix + e];
+  t.b = t2[pix + e];
+  return t;
+}
+__device__ __forceinline__ MapVals tab_rows_pick(const Chain &c, const TabRows &t, float det, const Rect &q) {
+  const DevParams *P = c.P;
+  // (the classes the unit terms would look up: load_map_vals_w())
+  const int c0 = __builtin_amdgcn_readfirstlane(value_to_class_tab(P, c.L.edges, 0, q.s)),
+            c1 = __builtin_amdgcn_readfirstlane(value_to_class_tab(P, c.L.edges + MPP_NCLASS, 1, q.r)),
+            c2 = __builtin_amdgcn_readfirstlane(value_to_class_tab(P, c.L.edges + 2 * MPP_NCLASS, 2, q.a));
+  MapVals v;
+  v.det = det; v.m0 = v.m1 = v.m2 = 0.f; v.tab = 1;
+  v.r0 = readlane_d(t.a, c0); v.r1 = readlane_d(t.a, MPP_NCLASS + c1); v.r2 = readlane_d(t.b, c2);
+  return v;
+}
 
 // draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
 // w: the step's Philox blocks 0 and 1.  The uniform of the accept test comes from words 6, 7 -- except for the
 // kernels that use all eight words themselves (the two births, split): only they pay for block 2.
 template <bool LANE>
 __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
-                              uint64_t step, uint32_t chain) {
+                              uint64_t step, uint32_t chain, MapVals *pmv) {
   const DevParams *P = c.P;
   double uk = u53(w[0], w[1]);
   int k = 0;
@@ -1153,8 +1198,12 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     r.ax = row; r.ay = col;
     // marks, and on the way the birth density of the drawn point (shape_samplers.py:103-108; same operation
     // order as birth_density())
-    double d = (double)c.t.det[(size_t)row * c.h.W + col] / tot;
+    const float detv = c.t.det[(size_t)row * c.h.W + col];
+    double d = (double)detv / tot;
     const uint32_t w5 = w[5], w6 = w[6], w7 = w[7];
+    const bool pre = !LANE && c.t.rm[0] != nullptr;
+    TabRows tr{0.0, 0.0};
+    if (pre) tr = tab_rows_request(c, ((size_t)row * c.h.W + col) * MPP_NCLASS);
     if (LANE) {
 #pragma clang loop unroll(disable)
       for (int k = 0; k < 3; ++k) {
@@ -1175,6 +1224,7 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     }
     r.qf = d * ((double)c.h.H * (double)c.h.W * 32768.0);
     *keep = KEEP_QF | (LANE ? 0 : KEEP_EDGE_ANGLE);
+    if (pre) { *pmv = tab_rows_pick(c, tr, detv, Rect{row, col, r.as, r.ar, r.aa}); *keep |= KEEP_MV; }
     DBPROF(15);
     return;
   }
@@ -1215,11 +1265,16 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     int pid = (int)mulhi32(w[3], 3u), cls;
     const int oc = value_to_class_tab(P, c.L.edges + pid * MPP_NCLASS, pid, mark_of(q, pid));
     double pb = 0.0;
+    const bool pre = !LANE && c.t.rm[0] != nullptr;
+    TabRows tr{0.0, 0.0};
+    float detv = 0.f;
+    if (pre) { detv = c.t.det[(size_t)q.x * c.h.W + q.y]; tr = tab_rows_request(c, ((size_t)q.x * c.h.W + q.y) * MPP_NCLASS); }
     r.qf = row_prob(c, pid, q.x, q.y, 0, true, u32d(w[4]), &cls, oc, &pb);
     r.qb = pb;
     set_mark(q, pid, c.L.edges[pid * MPP_NCLASS + cls]);
     r.pid = pid; r.ncls = cls; r.acls = cls;
     *keep = (pid == 2 ? KEEP_SIZE : KEEP_TRIG) | KEEP_QFB | (pid == 2 ? KEEP_EDGE_ANGLE : 0);
+    if (pre) { *pmv = tab_rows_pick(c, tr, detv, q); *keep |= KEEP_MV; }
   }
   // (materialised here through an empty asm: in the traced instantiation the compiler otherwise lost the row of the
   // data-driven transform branch -- r.ax came out as 0 -- when the kernel grew; ROCm 7.2 hipcc)
@@ -1327,19 +1382,21 @@ __device__ void write_slot(const Chain &c, int slot, const Rec &q) {
 #define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
 template <bool LANE, bool FAST = false>
 __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
-                         unsigned long long *prof) {
+                         const MapVals &pmv, unsigned long long *prof) {
   unsigned long long pt_ = clock64();
 #else
 #define EPROF(i)
 template <bool LANE, bool FAST = false>
-__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply) {
+__device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
+                         const MapVals &pmv) {
 #endif
   const DevParams *P = c.P;
   const Lds &L = c.L;
   // the score-map values of the proposed rectangle: requested first, used after the densities and the trigonometry
   MapVals mv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
 #ifndef MPP_NO_HOIST
-  if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
+  if (keep & KEEP_MV) mv = pmv;
+  else if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
 #endif
   proposal_densities(c, r, tracing, keep, !LANE);
   EPROF(4);

@@ -151,6 +151,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
       for (int i = 0; i < ri; ++i) if (T > T_target) T *= alpha;          // temperature of step `my`
       r.valid = 1;
       int keep = 0;
+      MapVals pmv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
       if (tape) {
         const mpp_proposal &tp = tape[tr0 + my];
         r.kernel = tp.kernel; r.tidx = tp.target; r.tslot = -1;
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
 #pragma unroll
         for (uint32_t b = 0; b < 2; ++b)
           philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), b, chain_t, k0, k1, w + 4 * b);
-        draw_proposal<LANE>(c, w, n, r, &keep, k0, k1, s, chain_t);
+        draw_proposal<LANE>(c, w, n, r, &keep, k0, k1, s, chain_t, &pmv);
         if (SM && r.kernel >= MPP_K_SPLIT) {
           int e = 0;
           sm_draw(c, r, ri, n, w, k0, k1, s, chain_t, &e);
@@ -217,9 +218,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         }
       } else if (r.valid) {
 #ifdef MPP_PROFILE
-        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, prof_);
+        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, pmv, prof_);
 #else
-        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round);
+        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, pmv);
 #endif
       }
 #ifdef MPP_PROFILE
