@@ -45,7 +45,14 @@ enum {
   MPP_U_MARK_REMAP = 3,  /* p[0]=k p[1]=coef p[2]=icpt           (calib_marks=True)                     */
   MPP_U_AREA = 4,        /* p[0]=min p[1]=max: max(0,min-A,A-max)             prior_energies.py:53-67  */
   MPP_U_RATIO_PRIOR = 5, /* p[0]=target: |target-ratio|                       prior_energies.py:70-78  */
-  MPP_U_CONST = 6        /* p[0]=c (the unit energy of the reference's unit tests)                      */
+  MPP_U_CONST = 6,       /* p[0]=c (the unit energy of the reference's unit tests)                      */
+  /* the classic image energies of the contrast setup (energy_setups/energy_setup_contrast.py:29-105): they read the
+   * picture given with mpp_set_image, not a score map.  Chains with one of them run the extended kernel (spec_waves 1 or 8). */
+  MPP_U_CONTRAST = 7,    /* p = {measure, dilation, gap, erode, thresh, fac, default_value}; measure: 0 lafarge, 1 craciun,
+                            2 craciun2, 3 mean, 4 t-test, 5 debug: fac*measure(fill pixels, rim pixels) summed over the
+                            channels - thresh                                  energies/classics.py:100-196 */
+  MPP_U_GRADIENT = 8     /* p = {thresh, eps}: -|mean(grad . outline normal)| - thresh; the image holds np.gradient of
+                            the picture, [H][W][C][2]                          energies/classics.py:199-235 */
 };
 /* pair energies: prior_energies.py */
 enum {
@@ -142,6 +149,11 @@ int64_t mpp_get_option(mpp_ctx *ctx, const char *name);
  * det: [n_tiles][H][W] float32; m0..m2: [n_tiles][H][W][32] float32 (size, ratio, angle). */
 int mpp_set_maps(mpp_ctx *ctx, int n_tiles, int H, int W, const float *det, const float *m0,
                  const float *m1, const float *m2, int on_device);
+/* the picture the classic image energies read (ImageWMaps.image, custom_types/image_w_maps.py:11-22, as prepared by
+ * ContrastEnergy.__post_init__ / GradientEnergy.__post_init__, classics.py:113-149, :207-215): img [n_tiles][H][W][C]
+ * float32, after mpp_set_maps (same n_tiles, H, W); C = 1 or 3 for MPP_U_CONTRAST, 2 or 6 (np.gradient, [..][C/2][2]) for
+ * MPP_U_GRADIENT.  on_device: borrowed.  Dropped by the next mpp_set_maps. */
+int mpp_set_image(mpp_ctx *ctx, int n_tiles, int C, const float *img, int on_device);
 int mpp_set_model(mpp_ctx *ctx, const mpp_model *model, const mpp_mappings *mappings);
 /* make_kernels(image_data, intensity, rng): intensity[n_tiles] = max(1,len(init)) (sample_rjmcmc.py:68) */
 int mpp_set_kernels(mpp_ctx *ctx, const mpp_kernels *kernels, const double *intensity);

@@ -95,3 +95,38 @@ def calibrate_min_area(gt_configs, quantile: float = 0.01):
     """``energy_calibration.py:159-185``: the 1 % and 99 % quantiles of the ground-truth areas"""
     areas = np.array([p.length * p.width for conf in gt_configs for p in conf], dtype=float)
     return float(np.quantile(areas, quantile)), float(np.quantile(areas, 1 - quantile))
+
+
+def calibrate_contrast_threshold(contrast_energy_maker, image_configs, rng: np.random.Generator, target: str = "f1",
+                                 device: int = 0) -> float:
+    """``energy_setup_contrast.py:165-205``: the classic image energy of every ground-truth rectangle against that of
+    4x as many random rectangles; the threshold of the best F-score on 100 thresholds between the extreme values, negated.
+    The energies are evaluated on the GPU (``energies.classic_values``); the random rectangles consume ``rng`` exactly as
+    the reference does (position, size, ratio, angle per rectangle)."""
+    from .energies import classic_values
+    from .shapes import Rectangle
+    x, y = [], []
+    for image_data in image_configs:
+        term = contrast_energy_maker(image_data, detection_thresh=0.0)
+        gt = list(image_data.gt_config)
+        H, W = np.asarray(image_data.image).shape[:2]
+        rd = []
+        for _ in range(4 * len(gt)):
+            rd.append(Rectangle(x=int(rng.integers(0, H)), y=int(rng.integers(0, W)), size=float(rng.normal(8, 1.0)),
+                                ratio=float(np.clip(rng.normal(0.5, 0.1), 0.1, 1)), angle=float(rng.uniform(0, np.pi))))
+        vals = -classic_values(term, gt + rd, getattr(image_data, "mappings", None), device=device)
+        x.append(vals)
+        y.append(np.array([True] * len(gt) + [False] * len(rd)))
+    x, y = np.concatenate(x), np.concatenate(y).astype(bool)
+    thresholds = np.linspace(np.min(x), np.max(x), 100)
+    precision, recall = [], []
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for t in thresholds:
+            pos = x > t
+            tp, fp = np.sum(pos & y), np.sum(pos & ~y)
+            precision.append(tp / (tp + fp))
+            recall.append(tp / np.sum(y))
+    pr = list(zip(precision, recall))
+    scores = {"f1": [2 * p * r / (p + r) if (p + r) > 0 else 0 for p, r in pr],
+              "f2": [f_beta(p, r, 2.0) for p, r in pr], "f0.5": [f_beta(p, r, 0.5) for p, r in pr]}
+    return float(-thresholds[int(np.argmax(scores[target]))])

@@ -65,6 +65,9 @@ struct mpp_ctx {
   int n_tiles = 0, H = 0, W = 0;
   bool maps_borrowed = false;
   float *det = nullptr, *m[3] = {nullptr, nullptr, nullptr};
+  float *img = nullptr;              // the picture behind the classic image energies (mpp_set_image), [n_maps][H][W][img_c]
+  int img_c = 0;
+  bool img_borrowed = false;
   double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
   bool box_dirty = true;
   int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
@@ -143,7 +146,7 @@ static const char *chain_error_text(int e) {
 }
 
 // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections; 5: mpp_set_chain_keys, options auto_grow / remap_table
-extern "C" int mpp_abi_version(void) { return 5; }
+extern "C" int mpp_abi_version(void) { return 6; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -176,6 +179,8 @@ static void free_tiles(mpp_ctx *c) {
     for (int k = 0; k < 3; ++k) if (c->m[k]) (void)hipFree(c->m[k]);
   }
   c->det = nullptr; c->m[0] = c->m[1] = c->m[2] = nullptr;
+  if (c->img && !c->img_borrowed) (void)hipFree(c->img);
+  c->img = nullptr; c->img_c = 0; c->img_borrowed = false;
   for (int k = 0; k < 3; ++k) if (c->remap[k]) { (void)hipFree(c->remap[k]); c->remap[k] = nullptr; }
   c->remap_dirty = true;
   if (c->boxsum) { (void)hipFree(c->boxsum); c->boxsum = nullptr; }
@@ -326,6 +331,17 @@ extern "C" int mpp_set_model(mpp_ctx *c, const mpp_model *model, const mpp_mappi
   for (int k = 0; k < 3; ++k)
     for (int i = 1; i < MPP_NCLASS; ++i)
       if (!(maps->edges[k][i] > maps->edges[k][i - 1])) return fail(c, -1, "mark %d: bin edges must increase", k);
+  for (int k = 0; k < model->n_unit; ++k) {
+    const mpp_unit_term &t = model->unit[k];
+    if (t.kind != MPP_U_CONTRAST && t.kind != MPP_U_GRADIENT) continue;
+    // the rasteriser works on a 96 x 128 pixel window: the largest rectangle (size = vmax, ratio -> 0) must fit with its margins
+    if (!(maps->vmax[0] <= 36.0)) return fail(c, -1, "unit term %d: the classic image energies need size marks <= 36 px", k);
+    if (t.kind == MPP_U_CONTRAST) {
+      const int measure = (int)t.p[0], dil = (int)t.p[1], gap = (int)t.p[2], ero = (int)t.p[3];
+      if (measure < 0 || measure > 5 || dil < 1 || dil > 4 || gap < 0 || gap > 2 || ero < 0 || ero > 2)
+        return fail(c, -1, "unit term %d: contrast energy wants measure 0..5, dilation 1..4, gap 0..2, erode 0..2", k);
+    }
+  }
   c->hp.model = *model;
   c->hp.maps = *maps;
   c->have_model = true;
@@ -407,9 +423,49 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   return 0;
 }
 
+static bool has_classic(const mpp_model &M, int *want_gradient = nullptr) {
+  bool any = false;
+  for (int k = 0; k < M.n_unit; ++k) {
+    if (M.unit[k].kind == MPP_U_CONTRAST) any = true;
+    if (M.unit[k].kind == MPP_U_GRADIENT) { any = true; if (want_gradient) *want_gradient = 1; }
+  }
+  return any;
+}
+
+extern "C" int mpp_set_image(mpp_ctx *c, int n_tiles, int C, const float *img, int on_device) {
+  if (!c) return -1;
+  if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
+  if (n_tiles != c->n_maps) return fail(c, -1, "mpp_set_image: %d tiles given, the ctx holds %d", n_tiles, c->n_maps);
+  if (!img || (C != 1 && C != 2 && C != 3 && C != 6)) return fail(c, -1, "mpp_set_image: C must be 1, 2, 3 or 6");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->img && !c->img_borrowed) (void)hipFree(c->img);
+  c->img = nullptr;
+  const size_t cnt = (size_t)c->n_maps * c->H * c->W * C;
+  if (on_device) c->img = const_cast<float *>(img);
+  else {
+    HIPCHK(c, dalloc(&c->img, cnt));
+    HIPCHK(c, hipMemcpyAsync(c->img, img, cnt * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  c->img_borrowed = on_device != 0;
+  c->img_c = C;
+  c->tiles_dirty = true;
+  return 0;
+}
+
 static int push_state(mpp_ctx *c) {
   if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
   if (!c->have_model) return fail(c, -1, "mpp_set_model has not been called");
+  {
+    int grad = 0;
+    if (has_classic(c->hp.model, &grad)) {
+      if (!c->img) return fail(c, -1, "the model has a classic image energy: mpp_set_image has not been called");
+      if (grad ? (c->img_c != 2 && c->img_c != 6) : (c->img_c != 1 && c->img_c != 3))
+        return fail(c, -1, "the image has %d channels: the %s energy wants %s", c->img_c, grad ? "gradient" : "contrast",
+                    grad ? "2 or 6 (np.gradient)" : "1 or 3");
+    }
+  }
   HIPCHK(c, hipSetDevice(c->device));
   if (c->tiles_dirty) {
     const size_t hw = (size_t)c->H * c->W;
@@ -424,6 +480,8 @@ static int push_state(mpp_ctx *c) {
       r.boxsum = (const MPP_GLOBAL double *)(c->boxsum + m * hw);
       for (int k = 0; k < 3; ++k)
         r.rm[k] = c->remap[k] ? (const MPP_GLOBAL double *)(c->remap[k] + m * hw * MPP_NCLASS) : nullptr;
+      r.img = c->img ? (const MPP_GLOBAL float *)(c->img + m * hw * (size_t)c->img_c) : nullptr;
+      r.img_c = c->img_c; r._pad_img = 0;
       r.px = c->px + (size_t)t * c->cap; r.py = c->py + (size_t)t * c->cap;
       r.ps = c->ps + (size_t)t * c->cap; r.pr = c->pr + (size_t)t * c->cap; r.pa = c->pa + (size_t)t * c->cap;
       r.n = c->n + t; r.T = c->T + 3 * (size_t)t; r.step = c->step + t; r.err = c->errd + t;
@@ -827,8 +885,8 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   // the row level of the birth CDF goes to LDS when it fits and the chain speculates (it shortens the slowest
   // wave of a round); throughput launches of one-wave chains keep their LDS for occupancy
   c->hp.rowbase_lds = (c->H <= 1024 && (c->lanes > 0 || c->spec > 1)) ? 1 : 0;
-  if (c->hp.n_kernels > MPP_K_SPLIT && !(c->lanes == 0 && (c->spec == 1 || c->spec == 8)))
-    return fail(c, -1, "the split / merge kernels are built for spec_waves 1 or 8 with spec_lanes 0");
+  if ((c->hp.n_kernels > MPP_K_SPLIT || has_classic(c->hp.model)) && !(c->lanes == 0 && (c->spec == 1 || c->spec == 8)))
+    return fail(c, -1, "the split / merge kernels and the classic image energies are built for spec_waves 1 or 8 with spec_lanes 0");
   mpp_launch_set_until(c->stream, c->d_tiles, tile0, grid, (long long)n_steps, c->until);
   HIPCHK(c, hipGetLastError());
   long long trace_base = 0;

@@ -1380,13 +1380,13 @@ __device__ void write_slot(const Chain &c, int slot, const Rec &q) {
 // dE, and the accept decision for population n at temperature T
 #ifdef MPP_PROFILE
 #define EPROF(i) do { unsigned long long n_ = clock64(); if (c.wave == 0) prof[i] += n_ - pt_; pt_ = n_; } while (0)
-template <bool LANE, bool FAST = false>
+template <bool LANE, bool FAST = false, bool EXT = false>
 __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
                          const MapVals &pmv, unsigned long long *prof) {
   unsigned long long pt_ = clock64();
 #else
 #define EPROF(i)
-template <bool LANE, bool FAST = false>
+template <bool LANE, bool FAST = false, bool EXT = false>
 __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double T, bool tracing, bool apply,
                          const MapVals &pmv) {
 #endif
@@ -1420,7 +1420,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
 #ifdef MPP_NO_HOIST
       mv = load_map_vals_w(P, c.h.W, c.t, L.edges, add);
 #endif
-      unit_part_mv(P, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
+      unit_part_mv<EXT>(P, c.t, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
       r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;
       EPROF(6);
     }

@@ -1,0 +1,235 @@
+// Classic image energies of the contrast energy setup (models/mpp/energies/classics.py:100-238,
+// energy_setups/energy_setup_contrast.py:29-105): unit terms that look at the PICTURE under a rectangle instead of at a
+// score map.  Included by mpp_device.hpp.
+//
+// The reference rasterises with scikit-image 0.18.1 (draw.polygon: every pixel of the clipped bounding box put to the
+// even-odd crossing test of _shared/geometry.pyx; draw.polygon_perimeter: corners rounded half to even, one Bresenham
+// line per edge) and grows / shrinks the pixel set with its own 4-neighbour dilation (utils/morpho.py:9-19).  Here ONE
+// THREAD evaluates a rectangle on bit rows -- row i of the bounding box (plus a margin) is a 128-bit word:
+//  * the fill mask of a row is the XOR of "all columns left of the crossing" prefixes of the edges that span the row,
+//    which is exactly the parity the crossing test computes pixel by pixel (same float64 expression for the crossing);
+//  * a dilation step is  row | row << 1 | row >> 1 | row above | row below, clipped to the image;
+//  * the statistics walk the set bits in row-major order, two passes (mean, then variance), as numpy does.
+// These are slow-path terms (the reference's classical baseline): no wave cooperation, private arrays.
+#pragma once
+
+#define MPP_CL_ROWS 96        // bounding box of the largest rectangle the mappings allow (size <= 32) + margins
+#define MPP_CL_COLS 128
+#define MPP_CL_OUTLINE 320    // pixels of four Bresenham edges of such a rectangle
+
+struct Bits128 { unsigned long long lo, hi; };
+__device__ __forceinline__ Bits128 b_or(Bits128 a, Bits128 b) { return Bits128{a.lo | b.lo, a.hi | b.hi}; }
+__device__ __forceinline__ Bits128 b_and(Bits128 a, Bits128 b) { return Bits128{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ Bits128 b_andn(Bits128 a, Bits128 b) { return Bits128{a.lo & ~b.lo, a.hi & ~b.hi}; }
+__device__ __forceinline__ Bits128 b_xor(Bits128 a, Bits128 b) { return Bits128{a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ Bits128 b_shl1(Bits128 a) { return Bits128{a.lo << 1, (a.hi << 1) | (a.lo >> 63)}; }
+__device__ __forceinline__ Bits128 b_shr1(Bits128 a) { return Bits128{(a.lo >> 1) | (a.hi << 63), a.hi >> 1}; }
+__device__ __forceinline__ bool b_any(Bits128 a) { return (a.lo | a.hi) != 0ull; }
+// bits [0, k)
+__device__ __forceinline__ Bits128 b_prefix(int k) {
+  if (k <= 0) return Bits128{0ull, 0ull};
+  if (k >= 128) return Bits128{~0ull, ~0ull};
+  if (k >= 64) return Bits128{~0ull, k == 64 ? 0ull : ((1ull << (k - 64)) - 1ull)};
+  return Bits128{(1ull << k) - 1ull, 0ull};
+}
+
+struct ClGrid { int r0, c0, nr; Bits128 cols; };     // origin, rows in use, columns that lie inside the image
+
+// rect_to_poly's vertex order (base/shapes/rectangle.py:85-88): (+,+) (+,-) (-,-) (-,+) = corners 0, 3, 2, 1 of geo_corners()
+__device__ inline void cl_ref_corners(const Geo &g, double *r, double *c) {
+  double x[4], y[4];
+  geo_corners(g, x, y);
+  r[0] = x[0]; c[0] = y[0]; r[1] = x[3]; c[1] = y[3]; r[2] = x[2]; c[2] = y[2]; r[3] = x[1]; c[3] = y[1];
+}
+
+// utils/morpho.py:9-19, n_iter steps
+__device__ inline void cl_dilate(const ClGrid &G, int H, Bits128 *a, Bits128 *tmp, int n_iter) {
+  for (int it = 0; it < n_iter; ++it) {
+    for (int i = 0; i < G.nr; ++i) tmp[i] = a[i];
+    for (int i = 0; i < G.nr; ++i) {
+      const int row = G.r0 + i;
+      if (row < 0 || row >= H) continue;
+      Bits128 v = b_or(tmp[i], b_or(b_shl1(tmp[i]), b_shr1(tmp[i])));
+      if (i > 0) v = b_or(v, tmp[i - 1]);
+      if (i + 1 < G.nr) v = b_or(v, tmp[i + 1]);
+      a[i] = b_and(v, G.cols);
+    }
+  }
+}
+__device__ inline int cl_count(const ClGrid &G, const Bits128 *a) {
+  int n = 0;
+  for (int i = 0; i < G.nr; ++i) n += __popcll(a[i].lo) + __popcll(a[i].hi);
+  return n;
+}
+// mean and (population) variance of channel ch over the pixels of a mask, row-major
+__device__ inline void cl_stats(const ClGrid &G, const Bits128 *m, const MPP_GLOBAL float *img, int W, int C, int ch,
+                                double *mean, double *var, int *cnt) {
+  double s = 0.0;
+  int n = 0;
+  for (int i = 0; i < G.nr; ++i)
+    for (int h = 0; h < 2; ++h) {
+      unsigned long long w = h ? m[i].hi : m[i].lo;
+      while (w) {
+        const int j = __ffsll((long long)w) - 1 + 64 * h;
+        w &= w - 1;
+        s += (double)img[((size_t)(G.r0 + i) * W + (G.c0 + j)) * C + ch];
+        ++n;
+      }
+    }
+  const double mu = s / (double)n;
+  double v = 0.0;
+  for (int i = 0; i < G.nr; ++i)
+    for (int h = 0; h < 2; ++h) {
+      unsigned long long w = h ? m[i].hi : m[i].lo;
+      while (w) {
+        const int j = __ffsll((long long)w) - 1 + 64 * h;
+        w &= w - 1;
+        const double d = (double)img[((size_t)(G.r0 + i) * W + (G.c0 + j)) * C + ch] - mu;
+        v += d * d;
+      }
+    }
+  *mean = mu; *var = v / (double)n; *cnt = n;
+}
+// the contrast measures, classics.py:13-97
+__device__ inline double cl_measure(int type, double mi, double mo, double vi, double vo, int ni, int no) {
+  const double eps = 1e-8, d = mi - mo;
+  switch (type) {
+    case 0: return sqrt((vo + vi) / ((double)(no + ni) * (d * d) + eps));                               // lafarge
+    case 1: return (d * d) / (4.0 * sqrt(vi + vo)) + (-0.5 * log((2.0 * sqrt(vi * vo)) / (vi + vo)));   // craciun
+    case 2: return (d * d) / (4.0 * sqrt(vi + vo) + eps);                                               // craciun2
+    case 3: return d * d;                                                                               // mean
+    case 4: return fabs(d) / sqrt((vi / (double)ni) + (vo / (double)no) + eps);                         // t-test
+    default: return fabs(d);                                                                            // debug
+  }
+}
+
+// ContrastEnergy.compute (classics.py:151-196); u.p = {measure, dilation, gap, erode, thresh, fac, default_value}
+__device__ __noinline__ double classic_contrast(const mpp_unit_term &u, const MPP_GLOBAL float *img, int C, int H, int W,
+                                                const Geo &g) {
+  double r[4], c[4];
+  cl_ref_corners(g, r, c);
+  double rmin = r[0], rmax = r[0], cmin = c[0], cmax = c[0];
+  for (int i = 1; i < 4; ++i) {
+    rmin = r[i] < rmin ? r[i] : rmin; rmax = r[i] > rmax ? r[i] : rmax;
+    cmin = c[i] < cmin ? c[i] : cmin; cmax = c[i] > cmax ? c[i] : cmax;
+  }
+  // skimage/draw/_draw.pyx _polygon: int(max(0, min)), int(ceil(max)), clipped to the shape
+  const int minr = (int)(rmin > 0.0 ? rmin : 0.0), minc = (int)(cmin > 0.0 ? cmin : 0.0);
+  int maxr = (int)ceil(rmax), maxc = (int)ceil(cmax);
+  maxr = maxr > H - 1 ? H - 1 : maxr; maxc = maxc > W - 1 ? W - 1 : maxc;
+  if (maxr < minr || maxc < minc) return u.p[6];
+  const int dil = (int)u.p[1], gap = (int)u.p[2], ero = (int)u.p[3];
+  const int reach = (2 + ero) > (gap + dil) ? (2 + ero) : (gap + dil);
+  const int M = 1 + reach;
+  ClGrid G;
+  G.r0 = minr - M; G.c0 = minc - M; G.nr = maxr - minr + 1 + 2 * M;
+  const int nc = maxc - minc + 1 + 2 * M;
+  if (G.nr > MPP_CL_ROWS || nc > MPP_CL_COLS) return nan("");      // excluded by mpp_set_model (size range of the mappings)
+  {
+    // columns of the grid that are columns of the image
+    const int lo = G.c0 < 0 ? -G.c0 : 0, hi = (W - G.c0) < nc ? (W - G.c0) : nc;
+    G.cols = b_andn(b_prefix(hi), b_prefix(lo));
+  }
+  Bits128 fill[MPP_CL_ROWS], a[MPP_CL_ROWS], b[MPP_CL_ROWS];
+  const Bits128 window = b_andn(b_prefix(maxc - G.c0 + 1), b_prefix(minc - G.c0));
+  for (int i = 0; i < G.nr; ++i) {
+    const int row = G.r0 + i;
+    Bits128 acc{0ull, 0ull};
+    if (row >= minr && row <= maxr) {
+      const double y = (double)row;
+      int j = 3;
+      for (int e = 0; e < 4; ++e) {
+        if (((r[e] <= y) && (y < r[j])) || ((r[j] <= y) && (y < r[e]))) {
+          const double xc = (c[j] - c[e]) * (y - r[e]) / (r[j] - r[e]) + c[e];      // point_in_polygon's crossing
+          double k = ceil(xc) - (double)G.c0;            // columns x < xc  <=>  bit index < ceil(xc) - c0
+          k = k < 0.0 ? 0.0 : (k > 128.0 ? 128.0 : k);
+          acc = b_xor(acc, b_prefix((int)k));
+        }
+        j = e;
+      }
+      acc = b_and(acc, window);
+    }
+    fill[i] = acc;
+  }
+  if (cl_count(G, fill) == 0) return u.p[6];
+  if (ero > 0) {                                   // classics.py:178-182
+    for (int i = 0; i < G.nr; ++i) a[i] = fill[i];
+    cl_dilate(G, H, a, b, 2);
+    for (int i = 0; i < G.nr; ++i) a[i] = b_andn(a[i], fill[i]);
+    cl_dilate(G, H, a, b, ero);
+    for (int i = 0; i < G.nr; ++i) fill[i] = b_andn(fill[i], a[i]);
+    if (cl_count(G, fill) == 0) return u.p[6];
+  }
+  // a <- rim
+  if (gap > 0) {                                   // :187-190
+    Bits128 rim[MPP_CL_ROWS];
+    for (int i = 0; i < G.nr; ++i) a[i] = fill[i];
+    cl_dilate(G, H, a, b, gap);
+    for (int i = 0; i < G.nr; ++i) rim[i] = a[i];
+    cl_dilate(G, H, rim, b, dil);
+    for (int i = 0; i < G.nr; ++i) a[i] = b_andn(rim[i], a[i]);
+  } else {                                         // :191-193
+    for (int i = 0; i < G.nr; ++i) a[i] = fill[i];
+    cl_dilate(G, H, a, b, dil);
+    for (int i = 0; i < G.nr; ++i) a[i] = b_andn(a[i], fill[i]);
+  }
+  double val = 0.0;
+  for (int ch = 0; ch < C; ++ch) {
+    double mi, mo, vi, vo;
+    int ni, no;
+    cl_stats(G, fill, img, W, C, ch, &mi, &vi, &ni);
+    cl_stats(G, a, img, W, C, ch, &mo, &vo, &no);
+    val += u.p[5] * cl_measure((int)u.p[0], mi, mo, vi, vo, ni, no);
+  }
+  return val - u.p[4];
+}
+
+// skimage/draw/_draw.pyx _line; appends to (pr, pc) and returns the number of points
+__device__ inline int cl_line(int r0, int c0, int r1, int c1, short *pr, short *pc, int room) {
+  bool steep = false;
+  int r = r0, c = c0, dr = abs(r1 - r0), dc = abs(c1 - c0);
+  int sc = (c1 - c) > 0 ? 1 : -1, sr = (r1 - r) > 0 ? 1 : -1;
+  if (dr > dc) { steep = true; int t = c; c = r; r = t; t = dc; dc = dr; dr = t; t = sc; sc = sr; sr = t; }
+  if (dc + 1 > room) return -1;
+  int d = 2 * dr - dc;
+  for (int i = 0; i < dc; ++i) {
+    if (steep) { pr[i] = (short)c; pc[i] = (short)r; } else { pr[i] = (short)r; pc[i] = (short)c; }
+    while (d >= 0) { r += sr; d -= 2 * dc; }
+    c += sc; d += 2 * dr;
+  }
+  pr[dc] = (short)r1; pc[dc] = (short)c1;
+  return dc + 1;
+}
+// GradientEnergy.compute (classics.py:207-232); img = np.gradient of the picture, [H][W][C/2][2]; u.p = {thresh, eps}
+__device__ __noinline__ double classic_gradient(const mpp_unit_term &u, const MPP_GLOBAL float *img, int C, int H, int W,
+                                                const Geo &g) {
+  double r[5], c[5];
+  cl_ref_corners(g, r, c);
+  r[4] = r[0]; c[4] = c[0];                                   // polygon_clip closes the polygon ...
+  const int nv = (r[4] == r[3] && c[4] == c[3]) ? 4 : 5;      // ... and drops a repeated last vertex
+  short pr[MPP_CL_OUTLINE], pc[MPP_CL_OUTLINE];
+  int n = 0;
+  for (int i = 0; i + 1 < nv; ++i) {
+    const int k = cl_line((int)rint(r[i]), (int)rint(c[i]), (int)rint(r[i + 1]), (int)rint(c[i + 1]), pr + n, pc + n,
+                          MPP_CL_OUTLINE - n);
+    if (k < 0) return nan("");
+    n += k;
+  }
+  int m = 0;                                                   // _coords_inside_image
+  for (int i = 0; i < n; ++i)
+    if (pr[i] >= 0 && pr[i] < H && pc[i] >= 0 && pc[i] < W) { pr[m] = pr[i]; pc[m] = pc[i]; ++m; }
+  const double eps = u.p[1];
+  double s = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const int nx = i + 1 < m ? i + 1 : 0, pv = i > 0 ? i - 1 : m - 1;
+    const double t1r = (double)(pr[nx] - pr[i]), t1c = (double)(pc[nx] - pc[i]);
+    const double t2r = (double)(pr[pv] - pr[i]), t2c = (double)(pc[pv] - pc[i]);
+    const double n1r = -t1c, n1c = t1r, n2r = t2c, n2c = -t2r;
+    const double l1 = sqrt(n1r * n1r + n1c * n1c) + eps, l2 = sqrt(n2r * n2r + n2c * n2c) + eps;
+    const double nr = 0.5 * (n1r / l1 + n2r / l2), ncl = 0.5 * (n1c / l1 + n2c / l2);
+    const MPP_GLOBAL float *gp = img + ((size_t)pr[i] * W + pc[i]) * C;
+    for (int k = 0; k < C; ++k) s += (double)gp[k] * ((k & 1) ? ncl : nr);
+  }
+  const double mean = s / ((double)m * (double)C);
+  return -fabs(mean) - u.p[0];
+}

@@ -58,6 +58,9 @@ struct TileRef {
   // optional [H][W][32] tables of the remapped mark probabilities -2*sigmoid(coef_k*P_k+icpt_k)+1 (the reference builds
   // these maps once per tile, energy_setup_legacy.py:142-147); nullptr: the three sigmoids are evaluated per proposal
   const MPP_GLOBAL double *rm[3];
+  // the picture behind the classic image energies (mpp_set_image): [H][W][img_c] float32, or nullptr
+  const MPP_GLOBAL float *img;
+  int32_t img_c, _pad_img;
   // point configuration, dense slots (capacity cap)
   int32_t *px, *py;
   double *ps, *pr, *pa;
@@ -253,8 +256,17 @@ __device__ __forceinline__ float map_mark(const MapVals &v, int k) {
   return k == 0 ? a : (k == 1 ? b : c);
 }
 
-// one unit energy term of a rectangle
-__device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const Geo &g, const MapVals &mv) {
+#include "mpp_classics.hpp"
+
+// one unit energy term of a rectangle.  CL: the classic image energies are compiled in (the chain kernel's extended
+// instantiations and the from-scratch kernels); elsewhere the host never selects a kernel for a model that has them.
+template <bool CL = false>
+__device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const Geo &g, const MapVals &mv,
+                                    const TileRef &t, int H, int W) {
+  if (CL) {
+    if (u.kind == MPP_U_CONTRAST) return classic_contrast(u, t.img, t.img_c, H, W, g);
+    if (u.kind == MPP_U_GRADIENT) return classic_gradient(u, t.img, t.img_c, H, W, g);
+  }
   switch (u.kind) {
     case MPP_U_POSITION: {
       float e = -2.0f * (mv.det - (float)u.p[0]);   // float32, as numpy does
@@ -298,28 +310,31 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
 // lin = lin0 + sum_units coef*g*v ; gate = [v_gate <= thr]
 // (two entry points: with the score-map values already fetched -- the chain issues those loads as early as it knows the
 // pixel and the marks, so that their latency overlaps the proposal densities and the trigonometry -- and without)
-__device__ inline void unit_part_mv(const DevParams *P, const MapVals &mv, const Rect &q, const Geo &g, double *lin,
-                                    int *gate, double *vec_or_null) {
+template <bool CL = false>
+__device__ inline void unit_part_mv(const DevParams *P, const TileRef &t, const MapVals &mv, const Rect &q, const Geo &g,
+                                    double *lin, int *gate, double *vec_or_null) {
   const mpp_model &M = P->model;
+  const int H = P->H, W = P->W;
   // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
   double vg = 0.0;
   int gt = 1;
   if (M.gate_term >= 0) {
-    vg = unit_value(M.unit[M.gate_term], q, g, mv);
+    vg = unit_value<CL>(M.unit[M.gate_term], q, g, mv, t, H, W);
     gt = (vg <= M.gate_thr) ? 1 : 0;
   }
   double l = M.lin0;
   for (int k = 0; k < M.n_unit; ++k) {
-    double v = (k == M.gate_term) ? vg : unit_value(M.unit[k], q, g, mv);
+    double v = (k == M.gate_term) ? vg : unit_value<CL>(M.unit[k], q, g, mv, t, H, W);
     if (vec_or_null) vec_or_null[k] = v;
     l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
   }
   *lin = l; *gate = gt;
 }
+template <bool CL = false>
 __device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
                                  const Geo &g, double *lin, int *gate, double *vec_or_null) {
   const MapVals mv = load_map_vals(P, t, edges, q);
-  unit_part_mv(P, mv, q, g, lin, gate, vec_or_null);
+  unit_part_mv<CL>(P, t, mv, q, g, lin, gate, vec_or_null);
 }
 __device__ __forceinline__ double pair_part(const DevParams *P, int gate, double r0, double r1) {
   const mpp_model &M = P->model;

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
     Rect q{c.t.px[i], c.t.py[i], c.t.ps[i], c.t.pr[i], c.t.pa[i]};
     Geo g = make_geo(q);
     double lin; int gate;
-    unit_part(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
+    unit_part<SM>(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
     L.xy[i] = (q.x & 0xffff) | (q.y << 16);
     L.s[i] = q.s; L.r[i] = q.r; L.a[i] = q.a; L.ca[i] = g.ca; L.sa[i] = g.sa; L.hl[i] = g.hl; L.hw[i] = g.hw;
     L.rad[i] = geo_radius(g);
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         }
       } else if (r.valid) {
 #ifdef MPP_PROFILE
-        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, pmv, prof_);
+        evaluate<LANE, FAST, SM>(c, r, ri, keep, n, T, tracing, apply_round, pmv, prof_);
 #else
-        evaluate<LANE, FAST>(c, r, ri, keep, n, T, tracing, apply_round, pmv);
+        evaluate<LANE, FAST, SM>(c, r, ri, keep, n, T, tracing, apply_round, pmv);
 #endif
       }
 #ifdef MPP_PROFILE
@@ -622,7 +622,11 @@ static hipError_t launch_spec(hipStream_t st, int grid, size_t lds, const DevPar
                               int occ) {
   constexpr int BASE = (WAVES + 3) / 4;      // waves per SIMD one workgroup needs anyway
   const bool diag = tape || out || props;
-  if (P->n_kernels > MPP_K_SPLIT) {          // split / merge kernels in the mixture: built for 1 and 8 waves
+  bool classic = false;                      // a classic image energy among the unit terms (energies/classics.py)
+  for (int k = 0; k < P->model.n_unit; ++k)
+    classic = classic || P->model.unit[k].kind == MPP_U_CONTRAST || P->model.unit[k].kind == MPP_U_GRADIENT;
+  if (P->n_kernels > MPP_K_SPLIT || classic) {   // split / merge kernels in the mixture, or a classic image energy: the
+                                                 // extended instantiations, built for 1 and 8 waves
     if constexpr (LPW == 0 && (WAVES == 1 || WAVES == 8)) {
       if (diag) return launch_spec_d<WAVES, LPW, true, BASE, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);
       return launch_spec_d<WAVES, LPW, false, BASE, true>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, tape, trace_tile, out, props);

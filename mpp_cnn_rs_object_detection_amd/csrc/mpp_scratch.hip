@@ -60,7 +60,7 @@ __device__ double point_energy(const DevParams *P, const TileRef &t, int n, cons
   const mpp_model &M = P->model;
   Geo gu = make_geo(u);
   double lin; int gate;
-  unit_part(P, t, &P->maps.edges[0][0], u, gu, &lin, &gate, vec_or_null);
+  unit_part<true>(P, t, &P->maps.edges[0][0], u, gu, &lin, &gate, vec_or_null);
   double red[MPP_MAX_PAIR] = {0.0, 0.0};
   const int mi = (int)ceil(P->max_inter);
   auto visit = [&](int v) {                       // v < n: slot of the configuration, else added rectangle v - n

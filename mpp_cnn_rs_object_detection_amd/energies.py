@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 # unit term kinds (same numbering as include/mpp_hip.h)
-U_POSITION, U_SHAPE_REMAP, U_MARK_NEG, U_MARK_REMAP, U_AREA, U_RATIO_PRIOR, U_CONST = range(7)
+U_POSITION, U_SHAPE_REMAP, U_MARK_NEG, U_MARK_REMAP, U_AREA, U_RATIO_PRIOR, U_CONST, U_CONTRAST, U_GRADIENT = range(9)
 # pair term kinds
 P_OVERLAP, P_ALIGN, P_DIST_LE, P_DIST_LT = range(4)
 REDUCE_MAX, REDUCE_MIN = 0, 1
@@ -40,6 +40,8 @@ class UnitTerm:
     name: str
     kind: int
     params: Sequence[float] = ()
+    #: the prepared picture a classic image energy reads ([H, W, C] float32; ``contrast_term`` / ``gradient_term``)
+    image: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -257,6 +259,142 @@ class LegacyEnergySetup(EnergySetup):
                      params=[1.0 if self.rewarding_priors else 0.0]),
         ]
         return unit, pair
+
+
+# ---- classic image energies (reference ``energies/classics.py``) -----------------------------------------------------
+#: contrast_measure_type -> (device index, fac, default_value)   (classics.py:117-143)
+CONTRAST_MEASURES = {"lafarge": (0, 1.0, 1e1), "craciun": (1, -1.0, 0.0), "craciun2": (2, -1.0, 0.0),
+                     "mean": (3, -1.0, 0.0), "t-test": (4, -1.0, 0.0), "debug": (5, 1.0, -1.0)}
+
+
+def contrast_term(name: str, image, dilation: int, contrast_measure_type: str, gap: int = 0, rgb: bool = False,
+                  thresh: float = 0.0, erode: int = 0, normalize: bool = False) -> UnitTerm:
+    """``ContrastEnergy(...)`` (classics.py:100-149) as a term of the flat model: the measure's index, sign and default
+    value, and the picture ``compute`` reads -- the channel mean for ``rgb=False`` (taken BEFORE any normalisation, as the
+    reference does), the (optionally normalised) picture itself for ``rgb=True``."""
+    if contrast_measure_type not in CONTRAST_MEASURES:
+        raise ValueError(contrast_measure_type)
+    idx, fac, default = CONTRAST_MEASURES[contrast_measure_type]
+    image = np.asarray(image)
+    if not rgb:
+        pic = np.mean(image, axis=-1)[..., None]
+    else:
+        pic = image
+        if normalize:
+            pic = pic - np.mean(pic, axis=(0, 1))
+            pic = pic / np.mean(np.abs(pic), axis=(0, 1))
+    return UnitTerm(name, U_CONTRAST, [idx, int(dilation), int(gap), int(erode), float(thresh), fac, default],
+                    image=np.ascontiguousarray(pic, dtype=np.float32))
+
+
+def gradient_term(name: str, image, dilation: int = 1, eps: float = 1e-8, thresh: float = 0.0,
+                  rgb: bool = False) -> UnitTerm:
+    """``GradientEnergy(...)`` (classics.py:199-216): the picture handed to the device is ``np.gradient`` of the image,
+    laid out [H, W, C, 2]."""
+    image = np.asarray(image)
+    img = image if rgb else np.mean(image, axis=-1)
+    grad = np.moveaxis(np.array(np.gradient(img, axis=(0, 1))), 0, -1)
+    H, W = image.shape[:2]
+    return UnitTerm(name, U_GRADIENT, [float(thresh), float(eps)],
+                    image=np.ascontiguousarray(grad.reshape(H, W, -1), dtype=np.float32))
+
+
+def classic_image(unit_terms: Sequence[UnitTerm]):
+    """The picture of the classic image energy among ``unit_terms`` (at most one), or None."""
+    pics = [t.image for t in unit_terms if t.kind in (U_CONTRAST, U_GRADIENT)]
+    if len(pics) > 1:
+        raise ValueError("at most one classic image energy per model (they share the context's picture)")
+    if pics and pics[0] is None:
+        raise ValueError("a classic image energy without its picture: build it with contrast_term / gradient_term")
+    return pics[0] if pics else None
+
+
+def classic_values(term: UnitTerm, rects, mappings=None, device: int = 0) -> np.ndarray:
+    """``[energy.compute(u) for u in rects]`` for a classic image energy, on the GPU (one context, one call)."""
+    from .hip_api import MppContext
+    from .mappings import default_mappings
+    rects = list(rects)
+    if not rects:
+        return np.zeros(0)
+    H, W = term.image.shape[:2]
+    ctx = MppContext(device, point_capacity=max(256, len(rects)))
+    ctx.set_maps(np.zeros((H, W), np.float32), [np.zeros((H, W, 32), np.float32)] * 3)
+    ctx.set_image(term.image)
+    ctx.set_model(build_model_desc([term], [], None), mappings or default_mappings())
+    ctx.set_points(0, np.array([[u.x, u.y] for u in rects], np.int32),
+                   np.array([[u.size, u.ratio, u.angle] for u in rects], np.float64))
+    _, vec = ctx.total_energy(0, return_vectors=True)
+    return np.asarray(vec)[:, 0].copy()
+
+
+class ContrastMeasureEnergySetup(EnergySetup):
+    """Reference ``energy_setups/energy_setup_contrast.py:29-161``: one classic image energy + two priors, two pair terms."""
+    NAMES = ["ContrastEnergy", "OverlapPriorEnergy", "AlignmentPriorEnergy", "AreaPriorEnergy", "RatioPriorEnergy"]
+
+    def __init__(self, contrast_type: str, learn_threshold: bool = False, rewarding_priors: bool = True,
+                 manual_threshold=None):
+        if contrast_type != "gradient" and contrast_type not in CONTRAST_MEASURES:
+            raise ValueError(contrast_type)
+        self.energy_cal = None
+        self.contrast_type = contrast_type
+        self.rewarding_priors = rewarding_priors
+        self.learn_threshold = learn_threshold
+        self.manual_threshold = manual_threshold
+
+    @property
+    def energy_names(self):
+        return list(self.NAMES)
+
+    def _make_contrast_energy(self, image_data, detection_thresh) -> UnitTerm:
+        """``energy_setup_contrast.py:50-79``"""
+        thresh = detection_thresh if detection_thresh is not None else 0.0
+        image = np.asarray(image_data.image)
+        if self.contrast_type == "gradient":
+            return gradient_term(self.NAMES[0], image, dilation=1, rgb=True, thresh=thresh)
+        # (the reference draws this noise for every contrast type and uses it for 't-test' only: same calls on numpy's global stream)
+        noisy = np.clip(image + np.random.normal(0, 0.05, size=image.shape), 0, 1)
+        t = self.contrast_type
+        return contrast_term(self.NAMES[0], image if t != "t-test" else noisy, dilation=2,
+                             gap=1 if t != "craciun" else 0, erode=1 if t != "craciun" else 0,
+                             contrast_measure_type=t, rgb=t != "t-test", thresh=thresh, normalize=t == "t-test")
+
+    def make_energies(self, image_data=None):
+        c = self.energy_cal
+        unit = [
+            self._make_contrast_energy(image_data, c["detection_thresh"]),
+            UnitTerm(self.NAMES[3], U_AREA, [c["min_area"], c["max_area"]]),
+            UnitTerm(self.NAMES[4], U_RATIO_PRIOR, [0.5]),
+        ]
+        pair = [
+            PairTerm(self.NAMES[1], P_OVERLAP, max_dist=32.0, reduce=REDUCE_MAX),
+            PairTerm(self.NAMES[2], P_ALIGN, max_dist=16.0,
+                     reduce=REDUCE_MIN if self.rewarding_priors else REDUCE_MAX,
+                     params=[1.0 if self.rewarding_priors else 0.0]),
+        ]
+        return unit, pair
+
+    def calibrate(self, image_configs, rng, save_path: str = None):
+        """``energy_setup_contrast.py:107-141`` (the alignment histogram there is a figure only)"""
+        from . import calibration as C
+        thr = None
+        if self.learn_threshold:
+            thr = C.calibrate_contrast_threshold(self._make_contrast_energy, image_configs, rng)
+        elif self.manual_threshold is not None:
+            thr = self.manual_threshold
+        min_area, max_area = C.calibrate_min_area([c.gt_config for c in image_configs])
+        self.energy_cal = {"detection_thresh": thr, "min_area": min_area, "max_area": max_area}
+        if save_path:
+            with open(os.path.join(save_path, "calibration.json"), "w") as f:
+                json.dump({"detection_thresh": thr, "min_area": min_area, "max_area": max_area}, f, indent=1)
+
+    def load_calibration(self, save_dir: str):
+        with open(os.path.join(save_dir, "calibration.json")) as f:
+            d = json.load(f)
+        self.energy_cal = {k: d[k] for k in ("detection_thresh", "min_area", "max_area")}
+
+    @property
+    def detection_threshold(self):
+        return 0.5
 
 
 class NoCalibrationEnergySetup(EnergySetup):

@@ -23,7 +23,7 @@ MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 #: every symbol include/mpp_hip.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
-    "mpp_get_option", "mpp_set_maps", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
+    "mpp_get_option", "mpp_set_maps", "mpp_set_image", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
@@ -104,6 +104,7 @@ def load_library(path: Optional[str] = None):
         "mpp_set_option": (i32, [vp, C.c_char_p, i64]),
         "mpp_get_option": (i64, [vp, C.c_char_p]),
         "mpp_set_maps": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, i32]),
+        "mpp_set_image": (i32, [vp, i32, i32, vp, i32]),
         "mpp_set_model": (i32, [vp, C.POINTER(ModelC), C.POINTER(MappingsC)]),
         "mpp_set_kernels": (i32, [vp, C.POINTER(KernelsC), vp]),
         "mpp_set_points": (i32, [vp, i32, i32, vp, vp]),
@@ -275,6 +276,24 @@ class MppContext:
                                          1 if on_device else 0))
         self._keep = arrs if on_device else []
         self.n_tiles, self.shape = self.get_option("n_chains"), (H, W)     # = T * replicas
+
+    def set_image(self, img):
+        """The picture behind the classic image energies (``energies/classics.py``): [T,H,W,C] or [H,W,C] float32, numpy
+        (copied) or a torch tensor on this GPU (borrowed); after :meth:`set_maps`."""
+        on_device = _is_torch(img)
+        if on_device:
+            import torch
+            a = img.contiguous() if img.dtype == torch.float32 else img.float().contiguous()
+            if not a.is_cuda or a.device.index != self.device:
+                raise ValueError(f"a borrowed image must live on GPU {self.device}")
+        else:
+            a = np.ascontiguousarray(img, dtype=np.float32)
+        if a.ndim == 3:
+            a = a.reshape((1,) + tuple(a.shape))
+        if a.ndim != 4 or tuple(a.shape[1:3]) != tuple(self.shape):
+            raise ValueError(f"image of shape {tuple(a.shape)} does not match tiles {self.shape}")
+        self._check(self._L.mpp_set_image(self._h, int(a.shape[0]), int(a.shape[3]), _ptr(a), 1 if on_device else 0))
+        self._keep_img = a if on_device else None
 
     def set_model(self, desc: ModelDesc, mappings):
         m, mp = model_struct(desc), mappings_struct(mappings)

@@ -129,7 +129,7 @@ class MPPModel:
         elif kind == "no-calibration":
             self.energy_setup = E.NoCalibrationEnergySetup(**params)
         elif kind == "contrast":
-            raise NotImplementedError("energy_setup 'contrast' (reference energy_setup_contrast.py) is not built")
+            self.energy_setup = E.ContrastMeasureEnergySetup(**params)
         else:
             print("energy_setup must be one of : 'legacy', 'no-calibration', 'contrast'")
             raise ValueError(kind)

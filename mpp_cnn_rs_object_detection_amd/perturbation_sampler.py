@@ -207,6 +207,8 @@ def sample_multiple_kernel_perturbations(image_data: ImageWMaps, n_samples: int,
     unit, pair = energy_setup.make_energies(image_data)
     ctx = MppContext(device, point_capacity=max(256, 4 * len(start) + 64))
     ctx.set_maps(image_data.detection_map, image_data.param_dist_maps)
+    if E.classic_image(unit) is not None:
+        ctx.set_image(E.classic_image(unit))
     ctx.set_model(E.build_model_desc(unit, pair, None), image_data.mappings)
     ctx.set_kernels(make_kernels(image_data.mappings, intensity=1.0, use_split_merge=use_split_merge))
     ctx.set_option("force_accept", 1)
@@ -234,6 +236,8 @@ def _walks_batched(image_data, start, n_samples, n_iter, seed, unit, pair, use_s
     (same five values) count as kept, which is the aggregate's energy-relevant content"""
     wctx = MppContext(device, point_capacity=max(256, 4 * len(start) + 64), replicas=n_samples)
     wctx.set_maps(image_data.detection_map, image_data.param_dist_maps)
+    if E.classic_image(unit) is not None:
+        wctx.set_image(E.classic_image(unit))
     wctx.set_model(E.build_model_desc(unit, pair, None), image_data.mappings)
     xy = np.array([[p.x, p.y] for p in start], dtype=np.int32).reshape(-1, 2)
     mk = np.array([[p.size, p.ratio, p.angle] for p in start], dtype=np.float64).reshape(-1, 3)

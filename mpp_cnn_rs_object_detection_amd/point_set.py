@@ -63,6 +63,9 @@ class EPointsSet:
                 self._ctx.set_maps(image_data.detection_map, image_data.param_dist_maps)
             else:
                 self._ctx.set_maps(np.zeros((H, W), np.float32), [np.zeros((H, W, 32), np.float32)] * 3)
+            pic = E.classic_image(self.ue_constructors)        # the picture a classic image energy reads (classics.py)
+            if pic is not None:
+                self._ctx.set_image(pic)
         self._dirty = True
         for u in pts:
             self._check_bounds(u)

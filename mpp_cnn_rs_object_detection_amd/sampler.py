@@ -107,6 +107,12 @@ class TileBatchSampler:
             det = np.stack([np.asarray(t.detection_map, dtype=np.float32) for t in tiles])
             marks = [np.stack([np.asarray(t.param_dist_maps[k], dtype=np.float32) for t in tiles]) for k in range(3)]
         self.ctx.set_maps(det, marks)
+        if E.classic_image(unit) is not None:
+            # a classic image energy (contrast setup): every tile brings its own picture, prepared as the setup prescribes
+            self.ctx.set_image(np.stack([E.classic_image(energy_setup.make_energies(t)[0]) for t in tiles]))
+            if spec_waves not in (1, 8):
+                auto_spec = False
+                self.ctx.set_option("spec_waves", 8)
         if keys is not None:
             self.ctx.set_chain_keys(keys[0], keys[1])
         self.ctx.set_model(self.model, self.mappings)

@@ -7,7 +7,10 @@ this package, and only to check or to time it -- the product never does.
 
 Parity status: pinned (reference known answers + tapes recorded from the
 reference), except the shapely/GEOS polygon-intersection boundary which is
-pinned by analytic known answers (see ``mpp_oracle.h``).
+pinned by analytic known answers (see ``mpp_oracle.h``), and the scikit-image
+0.18.1 rasterisation behind the classic image energies (energies/classics.py),
+restated from its published algorithm: fixtures recorded from the reference
+over that restatement pin everything above the primitive.
 """
 from __future__ import annotations
 
@@ -112,6 +115,12 @@ def lib():
         L.orc_overlap.restype = C.c_double
         L.orc_overlap.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_naive_detection.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_set_image.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_contrast_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_outline.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_unit_value.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_unit_value.restype = C.c_double
         _lib = L
     return _lib
 
@@ -182,6 +191,37 @@ class Oracle:
         if getattr(self, "_h", None):
             lib().orc_destroy(self._h)
             self._h = None
+
+    # ---- classic image energies (energies/classics.py) -----------------------------------------------------------
+    def set_image(self, img):
+        """float32 [H][W][C] image behind ORC_U_CONTRAST (C = 1 or 3) / ORC_U_GRADIENT (np.gradient, [H][W][C/2][2])."""
+        img = np.ascontiguousarray(img, dtype=np.float32).reshape(self.shape[0], self.shape[1], -1)
+        lib().orc_set_image(self._h, img.shape[2], _ptr(img))
+
+    def contrast_masks(self, rect, dilation, gap, erode, cap=65536):
+        """(fill, rim) pixel lists [(row, col)] of ContrastEnergy.compute_masks, row-major."""
+        r = np.ascontiguousarray(rect, dtype=np.float64)
+        fill, rim = np.zeros((cap, 2), np.int32), np.zeros((cap, 2), np.int32)
+        nf, nr = C.c_int32(0), C.c_int32(0)
+        lib().orc_contrast_masks(self._h, _ptr(r), int(dilation), int(gap), int(erode), cap, _ptr(fill), C.byref(nf),
+                                 _ptr(rim), C.byref(nr))
+        return fill[:nf.value].copy(), rim[:nr.value].copy()
+
+    def outline(self, rect, eps=1e-8, cap=4096):
+        """(pixels [(row, col)], normals) of GradientEnergy.compute_outline_and_normal, in outline order."""
+        r = np.ascontiguousarray(rect, dtype=np.float64)
+        rc, nrm = np.zeros((cap, 2), np.int32), np.zeros((cap, 2), np.float64)
+        n = lib().orc_outline(self._h, _ptr(r), float(eps), cap, _ptr(rc), _ptr(nrm))
+        return rc[:n].copy(), nrm[:n].copy()
+
+    def unit_value(self, term, rect):
+        """one unit term (kind, gated, coef, params) of a rectangle (x, y, size, ratio, angle)."""
+        t = UnitTerm()
+        t.kind, t.gated, t.coef = int(term[0]), int(term[1]), float(term[2])
+        for j, p in enumerate(term[3]):
+            t.p[j] = float(p)
+        r = np.ascontiguousarray(rect, dtype=np.float64)
+        return float(lib().orc_unit_value(self._h, C.byref(t), _ptr(r)))
 
     def set_points(self, xy, marks):
         xy = np.ascontiguousarray(xy, dtype=np.int32).reshape(-1, 2)

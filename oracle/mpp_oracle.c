@@ -32,6 +32,7 @@ typedef struct { int32_t x, y; double s, r, a; } rect_t;
 struct orc_ctx {
   int H, W;
   float *det, *m[3];
+  float *img; int img_c;      /* the image behind the classic energies (orc_set_image): [H][W][img_c] */
   orc_model model;
   orc_kernels kern;
   double p_cum[ORC_NKERNEL];
@@ -177,6 +178,187 @@ static inline const float *mark_row(const orc_ctx *c, int k, int x, int y) {
 }
 static double sigmoid(double x) { return 1.0 / (1.0 + exp(-x)); } /* utils/math_utils.py:6 */
 
+
+/* -------------------------------------------------- classic image energies */
+/* models/mpp/energies/classics.py:100-238.  The rasterisation lives in scikit-image 0.18.1, which is absent from the
+ * container ("parity unpinned" at that primitive, as for shapely): restated here from its published algorithm --
+ * skimage/draw/_draw.pyx `_polygon` (every pixel of the clipped bounding box put to the even-odd crossing test
+ * `point_in_polygon` of skimage/_shared/geometry.pyx), `_line` (Bresenham) and draw.py `polygon_perimeter` (corners
+ * rounded half-to-even, the four edges in vertex order, closed).  utils/morpho.py:9-19 is the reference's own dilation
+ * (4-neighbourhood, clipped to the image after every iteration). */
+static void ref_corners(const rect_t *q, double r[4], double c[4]) {
+  /* rect_to_poly's vertex order (rectangle.py:85-88): (+,+) (+,-) (-,-) (-,+) = corners 0, 3, 2, 1 of rect_corners() */
+  double x[4], y[4];
+  static const int ord[4] = {0, 3, 2, 1};
+  rect_corners(q, x, y);
+  for (int i = 0; i < 4; ++i) { r[i] = x[ord[i]]; c[i] = y[ord[i]]; }
+}
+static int point_in_polygon(const double *xp, const double *yp, double x, double y) {
+  int c = 0, j = 3;
+  for (int i = 0; i < 4; ++i) {
+    if ((((yp[i] <= y) && (y < yp[j])) || ((yp[j] <= y) && (y < yp[i]))) &&
+        (x < (xp[j] - xp[i]) * (y - yp[i]) / (yp[j] - yp[i]) + xp[i])) c = !c;
+    j = i;
+  }
+  return c;
+}
+typedef struct { int r0, c0, nr, nc; unsigned char *fill, *rim, *t0, *t1; } cgrid_t;
+static void grid_dilate(const orc_ctx *c, const cgrid_t *g, unsigned char *a, unsigned char *tmp, int n_iter) {
+  for (int it = 0; it < n_iter; ++it) {
+    memcpy(tmp, a, (size_t)g->nr * g->nc);
+    for (int i = 0; i < g->nr; ++i)
+      for (int j = 0; j < g->nc; ++j) {
+        if (tmp[i * g->nc + j]) continue;
+        int on = (i > 0 && tmp[(i - 1) * g->nc + j]) || (i + 1 < g->nr && tmp[(i + 1) * g->nc + j]) ||
+                 (j > 0 && tmp[i * g->nc + j - 1]) || (j + 1 < g->nc && tmp[i * g->nc + j + 1]);
+        int r = g->r0 + i, cc = g->c0 + j;
+        if (on && r >= 0 && r < c->H && cc >= 0 && cc < c->W) a[i * g->nc + j] = 1;
+      }
+  }
+}
+/* ContrastEnergy.compute_masks (classics.py:171-193); returns 0 when the fill mask is empty */
+static int contrast_masks(const orc_ctx *c, const rect_t *q, int dilation, int gap, int erode, cgrid_t *g) {
+  double r[4], cc[4];
+  ref_corners(q, r, cc);
+  double rmin = r[0], rmax = r[0], cmin = cc[0], cmax = cc[0];
+  for (int i = 1; i < 4; ++i) {
+    if (r[i] < rmin) rmin = r[i]; if (r[i] > rmax) rmax = r[i];
+    if (cc[i] < cmin) cmin = cc[i]; if (cc[i] > cmax) cmax = cc[i];
+  }
+  int minr = (int)(rmin > 0 ? rmin : 0), maxr = (int)ceil(rmax), minc = (int)(cmin > 0 ? cmin : 0), maxc = (int)ceil(cmax);
+  if (maxr > c->H - 1) maxr = c->H - 1;
+  if (maxc > c->W - 1) maxc = c->W - 1;
+  const int M = 3 + (erode > gap + dilation ? erode : gap + dilation);
+  g->r0 = minr - M; g->c0 = minc - M;
+  g->nr = (maxr >= minr ? maxr - minr + 1 : 0) + 2 * M; g->nc = (maxc >= minc ? maxc - minc + 1 : 0) + 2 * M;
+  size_t sz = (size_t)g->nr * g->nc;
+  g->fill = (unsigned char *)calloc(sz, 1); g->rim = (unsigned char *)calloc(sz, 1);
+  g->t0 = (unsigned char *)calloc(sz, 1); g->t1 = (unsigned char *)calloc(sz, 1);
+  int n_fill = 0;
+  for (int rr = minr; rr <= maxr; ++rr)
+    for (int c_ = minc; c_ <= maxc; ++c_)
+      if (point_in_polygon(cc, r, (double)c_, (double)rr)) { g->fill[(rr - g->r0) * g->nc + (c_ - g->c0)] = 1; ++n_fill; }
+  if (n_fill == 0) return 0;
+  if (erode > 0) {                       /* :178-182 */
+    memcpy(g->t0, g->fill, sz);
+    grid_dilate(c, g, g->t0, g->t1, 2);
+    for (size_t i = 0; i < sz; ++i) g->t0[i] = g->t0[i] && !g->fill[i];     /* rim of the raw mask */
+    grid_dilate(c, g, g->t0, g->t1, erode);
+    n_fill = 0;
+    for (size_t i = 0; i < sz; ++i) { g->fill[i] = g->fill[i] && !g->t0[i]; n_fill += g->fill[i]; }
+    if (n_fill == 0) return 0;
+  }
+  if (gap > 0) {                         /* :187-190 */
+    memcpy(g->t0, g->fill, sz);
+    grid_dilate(c, g, g->t0, g->t1, gap);
+    memcpy(g->rim, g->t0, sz);
+    grid_dilate(c, g, g->rim, g->t1, dilation);
+    for (size_t i = 0; i < sz; ++i) g->rim[i] = g->rim[i] && !g->t0[i];
+  } else {                               /* :191-193 */
+    memcpy(g->rim, g->fill, sz);
+    grid_dilate(c, g, g->rim, g->t1, dilation);
+    for (size_t i = 0; i < sz; ++i) g->rim[i] = g->rim[i] && !g->fill[i];
+  }
+  return n_fill;
+}
+static void grid_free(cgrid_t *g) { free(g->fill); free(g->rim); free(g->t0); free(g->t1); }
+static void mask_stats(const orc_ctx *c, const cgrid_t *g, const unsigned char *m, int ch, double *mean, double *var, int *cnt) {
+  double s = 0.0; int n = 0;
+  for (int i = 0; i < g->nr; ++i) for (int j = 0; j < g->nc; ++j)
+    if (m[i * g->nc + j]) { s += (double)c->img[((size_t)(g->r0 + i) * c->W + (g->c0 + j)) * c->img_c + ch]; ++n; }
+  double mu = s / (double)n, v = 0.0;
+  for (int i = 0; i < g->nr; ++i) for (int j = 0; j < g->nc; ++j)
+    if (m[i * g->nc + j]) { double d = (double)c->img[((size_t)(g->r0 + i) * c->W + (g->c0 + j)) * c->img_c + ch] - mu; v += d * d; }
+  *mean = mu; *var = v / (double)n; *cnt = n;
+}
+/* the contrast measures, classics.py:13-97 */
+static double contrast_measure(int type, double mi, double mo, double vi, double vo, int ni, int no) {
+  const double eps = 1e-8, d = mi - mo;
+  switch (type) {
+    case 0: return sqrt((vo + vi) / ((double)(no + ni) * (d * d) + eps));                         /* lafarge :13-28 */
+    case 1: return (d * d) / (4.0 * sqrt(vi + vo)) + (-0.5 * log((2.0 * sqrt(vi * vo)) / (vi + vo)));   /* craciun :31-51 */
+    case 2: return (d * d) / (4.0 * sqrt(vi + vo) + eps);                                          /* craciun2 :67-82 */
+    case 3: return d * d;                                                                          /* mean :94-97 */
+    case 4: return fabs(d) / sqrt((vi / (double)ni) + (vo / (double)no) + eps);                    /* t-test :85-91 */
+    default: return fabs(d);                                                                       /* debug :57-64 */
+  }
+}
+/* ContrastEnergy.compute (classics.py:151-169): p = {measure, dilation, gap, erode, thresh, fac, default_value} */
+static double contrast_value(const orc_ctx *c, const orc_unit_term *t, const rect_t *q) {
+  cgrid_t g;
+  double val;
+  if (!contrast_masks(c, q, (int)t->p[1], (int)t->p[2], (int)t->p[3], &g)) val = t->p[6];
+  else {
+    val = 0.0;
+    for (int ch = 0; ch < c->img_c; ++ch) {
+      double mi, mo, vi, vo; int ni, no;
+      mask_stats(c, &g, g.fill, ch, &mi, &vi, &ni);
+      mask_stats(c, &g, g.rim, ch, &mo, &vo, &no);
+      val += t->p[5] * contrast_measure((int)t->p[0], mi, mo, vi, vo, ni, no);
+    }
+    val -= t->p[4];
+  }
+  grid_free(&g);
+  return val;
+}
+/* skimage/draw/_draw.pyx `_line` */
+static int bresenham(int r0, int c0, int r1, int c1, int *rr, int *cc) {
+  int steep = 0, r = r0, c = c0, dr = abs(r1 - r0), dc = abs(c1 - c0);
+  int sc = (c1 - c) > 0 ? 1 : -1, sr = (r1 - r) > 0 ? 1 : -1;
+  if (dr > dc) { steep = 1; int t = c; c = r; r = t; t = dc; dc = dr; dr = t; t = sc; sc = sr; sr = t; }
+  int d = 2 * dr - dc;
+  for (int i = 0; i < dc; ++i) {
+    if (steep) { rr[i] = c; cc[i] = r; } else { rr[i] = r; cc[i] = c; }
+    while (d >= 0) { r += sr; d -= 2 * dc; }
+    c += sc; d += 2 * dr;
+  }
+  rr[dc] = r1; cc[dc] = c1;
+  return dc + 1;
+}
+/* GradientEnergy.compute_outline_and_normal (classics.py:218-232); returns the number of outline pixels */
+static int outline_and_normals(const orc_ctx *c, const rect_t *q, double eps, int **pr_out, int **pc_out, double **nrm_out) {
+  double r[5], cc[5];
+  ref_corners(q, r, cc);
+  r[4] = r[0]; cc[4] = cc[0];                 /* polygon_clip closes the polygon */
+  int nv = 5;
+  if (r[4] == r[3] && cc[4] == cc[3]) nv = 4; /* its "last two vertices equal" rule */
+  int vr[5], vc[5], total = 0;
+  for (int i = 0; i < nv; ++i) { vr[i] = (int)rint(r[i]); vc[i] = (int)rint(cc[i]); }
+  for (int i = 0; i + 1 < nv; ++i) { int a = abs(vr[i + 1] - vr[i]), b = abs(vc[i + 1] - vc[i]); total += (a > b ? a : b) + 1; }
+  int *pr = (int *)malloc(sizeof(int) * (total + 1)), *pc = (int *)malloc(sizeof(int) * (total + 1));
+  int n = 0;
+  for (int i = 0; i + 1 < nv; ++i) n += bresenham(vr[i], vc[i], vr[i + 1], vc[i + 1], pr + n, pc + n);
+  int m = 0;                                  /* _coords_inside_image */
+  for (int i = 0; i < n; ++i)
+    if (pr[i] >= 0 && pr[i] < c->H && pc[i] >= 0 && pc[i] < c->W) { pr[m] = pr[i]; pc[m] = pc[i]; ++m; }
+  double *nrm = (double *)malloc(sizeof(double) * 2 * (m + 1));
+  for (int i = 0; i < m; ++i) {
+    int nx = i + 1 < m ? i + 1 : 0, pv = i > 0 ? i - 1 : m - 1;
+    double t1r = pr[nx] - pr[i], t1c = pc[nx] - pc[i];      /* tangent_1 */
+    double t2r = pr[pv] - pr[i], t2c = pc[pv] - pc[i];      /* tangent_2 after the two flips */
+    double n1r = -t1c, n1c = t1r, n2r = t2c, n2c = -t2r;    /* :224, :226 (expanded signs) */
+    double l1 = sqrt(n1r * n1r + n1c * n1c) + eps, l2 = sqrt(n2r * n2r + n2c * n2c) + eps;
+    nrm[2 * i] = 0.5 * (n1r / l1 + n2r / l2);
+    nrm[2 * i + 1] = 0.5 * (n1c / l1 + n2c / l2);
+  }
+  *pr_out = pr; *pc_out = pc; *nrm_out = nrm;
+  return m;
+}
+/* GradientEnergy.compute (classics.py:207-216): the image holds np.gradient of the picture, [H][W][C/2][2];
+ * p = {thresh, eps} */
+static double gradient_value(const orc_ctx *c, const orc_unit_term *t, const rect_t *q) {
+  int *pr, *pc; double *nrm;
+  int m = outline_and_normals(c, q, t->p[1], &pr, &pc, &nrm);
+  double s = 0.0;
+  for (int i = 0; i < m; ++i) {
+    const float *g = c->img + ((size_t)pr[i] * c->W + pc[i]) * c->img_c;
+    for (int k = 0; k < c->img_c; ++k) s += (double)g[k] * nrm[2 * i + (k & 1)];
+  }
+  double mean = s / ((double)m * (double)c->img_c);
+  free(pr); free(pc); free(nrm);
+  return -fabs(mean) - t->p[0];
+}
+
 /* -------------------------------------------------------------- unit terms */
 static double unit_value(const orc_ctx *c, const orc_unit_term *t, const rect_t *q) {
   switch (t->kind) {
@@ -209,6 +391,8 @@ static double unit_value(const orc_ctx *c, const orc_unit_term *t, const rect_t 
     }
     case ORC_U_RATIO_PRIOR: return fabs(t->p[0] - q->r);
     case ORC_U_CONST: return t->p[0];
+    case ORC_U_CONTRAST: return contrast_value(c, t, q);
+    case ORC_U_GRADIENT: return gradient_value(c, t, q);
   }
   return 0.0;
 }
@@ -382,7 +566,43 @@ void orc_destroy(orc_ctx *c) {
   for (int i = 0; i < nc; ++i) free(c->cell_items[i]);
   free(c->cell_items); free(c->cell_cnt); free(c->cell_cap);
   free(c->det); for (int k = 0; k < 3; ++k) free(c->m[k]);
+  free(c->img);
   free(c->cdf); free(c->pt); free(c->mark); free(c);
+}
+int orc_set_image(orc_ctx *c, int C, const float *img) {
+  free(c->img);
+  size_t n = (size_t)c->H * c->W * C;
+  c->img = (float *)malloc(n * sizeof(float));
+  memcpy(c->img, img, n * sizeof(float));
+  c->img_c = C;
+  return 0;
+}
+/* test hooks: the two pixel sets of ContrastEnergy.compute_masks / the outline of GradientEnergy (row, col pairs) */
+int orc_contrast_masks(orc_ctx *c, const double rect[5], int dilation, int gap, int erode, int cap, int32_t *fill_rc,
+                       int32_t *n_fill, int32_t *rim_rc, int32_t *n_rim) {
+  rect_t q = {(int32_t)rect[0], (int32_t)rect[1], rect[2], rect[3], rect[4]};
+  cgrid_t g;
+  int nf = 0, nr = 0;
+  if (contrast_masks(c, &q, dilation, gap, erode, &g))
+    for (int i = 0; i < g.nr; ++i) for (int j = 0; j < g.nc; ++j) {
+      if (g.fill[i * g.nc + j]) { if (nf < cap) { fill_rc[2 * nf] = g.r0 + i; fill_rc[2 * nf + 1] = g.c0 + j; } ++nf; }
+      if (g.rim[i * g.nc + j]) { if (nr < cap) { rim_rc[2 * nr] = g.r0 + i; rim_rc[2 * nr + 1] = g.c0 + j; } ++nr; }
+    }
+  grid_free(&g);
+  *n_fill = nf; *n_rim = nr;
+  return 0;
+}
+int orc_outline(orc_ctx *c, const double rect[5], double eps, int cap, int32_t *rc, double *normals) {
+  rect_t q = {(int32_t)rect[0], (int32_t)rect[1], rect[2], rect[3], rect[4]};
+  int *pr, *pc; double *nrm;
+  int m = outline_and_normals(c, &q, eps, &pr, &pc, &nrm);
+  for (int i = 0; i < m && i < cap; ++i) { rc[2 * i] = pr[i]; rc[2 * i + 1] = pc[i]; normals[2 * i] = nrm[2 * i]; normals[2 * i + 1] = nrm[2 * i + 1]; }
+  free(pr); free(pc); free(nrm);
+  return m;
+}
+double orc_unit_value(orc_ctx *c, const orc_unit_term *t, const double rect[5]) {
+  rect_t q = {(int32_t)rect[0], (int32_t)rect[1], rect[2], rect[3], rect[4]};
+  return unit_value(c, t, &q);
 }
 int orc_set_points(orc_ctx *c, int n, const int32_t *xy, const double *marks) {
   int nc = c->nx * c->ny;

@@ -13,6 +13,10 @@
  * rectangle-intersection area lives in shapely/GEOS, which is not in the
  * container; the recorded values used a Sutherland-Hodgman stand-in, so the
  * overlap term is pinned by analytic known answers instead (tests/test_geometry.py).
+ * UNPINNED likewise: the rasteriser of the classic image energies (ORC_U_CONTRAST / ORC_U_GRADIENT) lives in
+ * scikit-image 0.18.1, absent too; it is restated from that version's published algorithm, and everything above the
+ * primitive is pinned by values, masks, outlines and a chain the reference produced over the same restatement
+ * (tests/golden/classics_golden.npz, tape_contrast_96.npz).
  *
  * Each function cites the reference file:line it restates (paths relative to
  * /root/reference).
@@ -39,7 +43,10 @@ enum {
   ORC_U_MARK_REMAP = 3, /* p[0]=k p[1]=coef p[2]=icpt            (calib_marks=True)                   */
   ORC_U_AREA = 4,       /* p[0]=min p[1]=max : max(0,min-A,A-max) prior_energies.py:53-67             */
   ORC_U_RATIO_PRIOR = 5,/* p[0]=target : |target-ratio|           prior_energies.py:70-78             */
-  ORC_U_CONST = 6       /* p[0]=c  (the reference tests' TestUnitEnergy)                              */
+  ORC_U_CONST = 6,      /* p[0]=c  (the reference tests' TestUnitEnergy)                              */
+  ORC_U_CONTRAST = 7,   /* p = {measure, dilation, gap, erode, thresh, fac, default}; measure: 0 lafarge 1 craciun
+                           2 craciun2 3 mean 4 t-test 5 debug      energies/classics.py:100-196 (orc_set_image) */
+  ORC_U_GRADIENT = 8    /* p = {thresh, eps}; the image holds np.gradient of the picture  classics.py:199-235 */
 };
 /* pair term kinds */
 enum {
@@ -116,6 +123,13 @@ typedef struct orc_ctx orc_ctx;
 orc_ctx *orc_create(int H, int W, const float *det, const float *m0, const float *m1, const float *m2,
                     const orc_model *model, const orc_kernels *kernels);
 void orc_destroy(orc_ctx *c);
+/* the image the classic energies read, float32 [H][W][C] (copied): C = 1 or 3 for ORC_U_CONTRAST, np.gradient of the
+ * picture laid out [H][W][C/2][2] for ORC_U_GRADIENT */
+int orc_set_image(orc_ctx *c, int C, const float *img);
+int orc_contrast_masks(orc_ctx *c, const double rect[5], int dilation, int gap, int erode, int cap, int32_t *fill_rc,
+                       int32_t *n_fill, int32_t *rim_rc, int32_t *n_rim);
+int orc_outline(orc_ctx *c, const double rect[5], double eps, int cap, int32_t *rc, double *normals);
+double orc_unit_value(orc_ctx *c, const orc_unit_term *t, const double rect[5]);
 int orc_set_points(orc_ctx *c, int n, const int32_t *xy, const double *marks);
 int orc_get_points(orc_ctx *c, int cap, int32_t *xy, double *marks);
 int orc_count(orc_ctx *c);

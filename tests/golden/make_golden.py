@@ -122,8 +122,10 @@ class RecordingRNG:
         return v
 
 
-def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive", use_split_merge=False):
+def record_tape(tile, setup, comb, seed, rjmcmc_params, init="naive", use_split_merge=False, image=None):
     image_data = image_data_from(tile)
+    if image is not None:
+        image_data.image = image
     rng = RecordingRNG(np.random.default_rng(seed))
     stash = {}
     rows = []
@@ -573,6 +575,132 @@ def make_host_golden():
     print("wrote host_golden.npz", os.path.getsize(os.path.join(HERE, "host_golden.npz")) // 1024, "KiB")
 
 
+def make_classics_golden():
+    """The classic image energies (models/mpp/energies/classics.py) and the contrast energy setup
+    (energy_setups/energy_setup_contrast.py) run by the reference on a scene of the reference's image recipe: pixel masks
+    of ContrastEnergy.compute_masks, outlines and normals of GradientEnergy, the values of every contrast measure -- on the
+    float32 picture (what a user gets) and on the same picture as float64 (the reference then computes in float64: the
+    tight pin of the restatement) --, and per-point energy vectors of a configuration under the setup.
+    scikit-image is absent: `draw.polygon`, `draw.polygon_perimeter` come from tests/golden/_shim (restated from 0.18.1)."""
+    from models.mpp.energies.classics import ContrastEnergy, GradientEnergy
+    from models.mpp.energies.energy_setups import energy_setup_contrast as esc
+    from models.mpp.energies.combination.hierarchical import ManualHierarchicalEnergyCombinator
+
+    H = W = 96
+    img, gt_xy, gt_marks = synth.make_scene_image((H, W), n_rect=40, seed=5)
+    img64 = img.astype(np.float64)
+    rng = np.random.default_rng(77)
+    rects = [(int(x), int(y), float(m[0]), float(m[1]), float(m[2])) for (x, y), m in zip(gt_xy, gt_marks)]
+    for _ in range(60):       # random ones, some hanging over the border, some tiny, some as large as the mappings allow
+        rects.append((int(rng.integers(0, H)), int(rng.integers(0, W)), float(rng.uniform(0.3, 31.0) if rng.random() < 0.3
+                      else rng.normal(8, 2.0)), float(np.clip(rng.normal(0.5, 0.2), 0.1, 1)), float(rng.uniform(0, np.pi))))
+    rects += [(0, 0, 8.0, 0.5, 0.3), (H - 1, W - 1, 8.0, 0.5, 2.0), (0, W // 2, 12.0, 0.3, 1.2), (40, 40, 0.4, 0.5, 0.1),
+              (50, 50, 31.9, 0.1, 0.77), (20, 30, 8.0, 0.5, 0.0), (20, 30, 8.0, 1.0, float(np.pi / 4))]
+    R = [Rectangle(x, y, size=max(s, 0.05), ratio=r, angle=a) for x, y, s, r, a in rects]
+    out = {"image": img, "rects": np.array([[u.x, u.y, u.size, u.ratio, u.angle] for u in R], dtype=np.float64)}
+    types = ["lafarge", "craciun", "craciun2", "mean", "t-test", "debug"]
+    rs = np.random.RandomState(3)
+    noisy = np.clip(img + rs.normal(0, 0.05, size=img.shape), 0, 1)      # the picture the setup gives the t-test measure
+    out["noisy_image"] = noisy
+    mask_rows = {}
+    for t in types:
+        kw = dict(name="c", dilation=2, gap=1 if t != "craciun" else 0, erode=1 if t != "craciun" else 0,
+                  contrast_measure_type=t, rgb=t != "t-test", thresh=0.25, normalize=t == "t-test")
+        e32 = ContrastEnergy(image=img if t != "t-test" else noisy, **kw)
+        e64 = ContrastEnergy(image=img64 if t != "t-test" else noisy.astype(np.float64), **kw)
+        v32, v64 = [], []
+        with np.errstate(all="ignore"):
+            for u in R:
+                v32.append(float(e32.compute(u)))
+                v64.append(float(e64.compute(u)))
+        out[f"values32_{t}"], out[f"values64_{t}"] = np.array(v32), np.array(v64)
+        if t in ("lafarge", "craciun"):       # the two mask recipes: (dilation 2, gap 1, erode 1) and (2, 0, 0)
+            fills, rims, off = [], [], [0]
+            for u in R:
+                f, r = e32.compute_masks(u)
+                f = np.asarray(f).T.astype(np.int32).reshape(-1, 2)
+                r = np.asarray(r).T.astype(np.int32).reshape(-1, 2) if len(f) else np.zeros((0, 2), np.int32)
+                fills.append(f[np.lexsort((f[:, 1], f[:, 0]))]); rims.append(r[np.lexsort((r[:, 1], r[:, 0]))])
+            out[f"fill_{t}"] = np.concatenate(fills); out[f"fill_off_{t}"] = np.cumsum([0] + [len(f) for f in fills])
+            out[f"rim_{t}"] = np.concatenate(rims); out[f"rim_off_{t}"] = np.cumsum([0] + [len(r) for r in rims])
+    # gradient energy: rgb (as the setup builds it) and grey
+    for rgb in (True, False):
+        g32 = GradientEnergy(name="g", image=img, dilation=1, rgb=rgb, thresh=0.1)
+        g64 = GradientEnergy(name="g", image=img64, dilation=1, rgb=rgb, thresh=0.1)
+        with np.errstate(all="ignore"):
+            out[f"gradient32_{'rgb' if rgb else 'grey'}"] = np.array([g32.compute(u) for u in R])
+            out[f"gradient64_{'rgb' if rgb else 'grey'}"] = np.array([g64.compute(u) for u in R])
+    g = GradientEnergy(name="g", image=img, dilation=1, rgb=True, thresh=0.1)
+    outl, nrm = [], []
+    for u in R:
+        per, n3 = g.compute_outline_and_normal(u)
+        outl.append(np.asarray(per).T.astype(np.int32).reshape(-1, 2)); nrm.append(np.asarray(n3, dtype=np.float64).reshape(-1, 2))
+    out["outline"] = np.concatenate(outl); out["normals"] = np.concatenate(nrm)
+    out["outline_off"] = np.cumsum([0] + [len(o) for o in outl])
+    # the setup: names, term order, per-point energy vectors and combined energy of the ground truth + a few intruders
+    tile = synth.SynthTile(shape=(H, W), det=np.full((H, W), 0.5, np.float32),
+                           marks=[np.full((H, W, 32), 1 / 32, np.float32)] * 3, gt_xy=gt_xy, gt_marks=gt_marks)
+    data = image_data_from(tile)
+    data.image = img
+    weights = {"ContrastEnergy": 1.0, "OverlapPriorEnergy": 2.0, "AlignmentPriorEnergy": 0.5, "AreaPriorEnergy": 0.25,
+               "RatioPriorEnergy": 0.75}
+    for ctype in ("craciun2", "gradient"):
+        setup = esc.ContrastMeasureEnergySetup(contrast_type=ctype, manual_threshold=-0.05)
+        setup.energy_cal = esc.EnergiesCalibration(detection_thresh=-0.05, min_area=20.0, max_area=90.0)
+        np.random.seed(11)
+        ue, pe = setup.make_energies(data)
+        cfg = [Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2]))
+               for (x, y), m in zip(gt_xy, gt_marks)] + R[len(gt_xy):len(gt_xy) + 12]
+        pts = EPointsSet(points=cfg, support_shape=(H, W), unit_energies_constructors=ue, pair_energies_constructors=pe)
+        comb = ManualHierarchicalEnergyCombinator(weights_dict=weights, indicator_energy="ContrastEnergy",
+                                                  detection_threshold=0.0)
+        names = setup.energy_names
+        with np.errstate(all="ignore"):
+            vec = pts.energy_graph.compute_subset(pts.points, return_vector=True)
+            order = [u for u in pts.points]
+            out[f"setup_names_{ctype}"] = np.array(names)
+            out[f"setup_cfg_{ctype}"] = np.array([[u.x, u.y, u.size, u.ratio, u.angle] for u in order], dtype=np.float64)
+            out[f"setup_vec_{ctype}"] = np.array([vec[k] for k in names], dtype=np.float64).T
+            out[f"setup_total_sum_{ctype}"] = float(pts.total_energy())
+            out[f"setup_total_comb_{ctype}"] = float(pts.energy_graph.compute_subset(pts.points, energy_combinator=comb))
+            out[f"setup_papangelou_{ctype}"] = np.array(
+                [pts.papangelou(u, energy_combinator=comb, remove_u_from_point_set=True, return_energy_delta=True)
+                 for u in order], dtype=np.float64)
+    out["setup_weights"] = np.array([weights[n] for n in esc.ContrastMeasureEnergySetup.NAMES])
+    np.savez_compressed(os.path.join(HERE, "classics_golden.npz"), **out)
+    print("classics_golden.npz:", len(R), "rectangles;", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+def make_contrast_tape():
+    """A chain of the reference sampler under the CONTRAST energy setup (energy_setup_contrast.py:29-105, craciun2 measure,
+    manual hierarchical combinator with the contrast term gating the priors) on a 96x96 tile whose picture shows the
+    tile's ground-truth rectangles.  The picture is handed over as float64 (exactly the float32 values stored in the
+    fixture), so the reference's contrast statistics are float64 arithmetic and the recorded dE pin the restatement
+    tightly; scikit-image's rasteriser comes from tests/golden/_shim."""
+    from models.mpp.energies.energy_setups import energy_setup_contrast as esc
+    from models.mpp.energies.combination.hierarchical import ManualHierarchicalEnergyCombinator
+    from skimage.draw import polygon
+    t = synth.make_tile(96, 20, tile_id=7, noise=0.15)
+    rng = np.random.default_rng(99)
+    img = np.full((96, 96, 3), 0.5)
+    for k, ((x, y), m) in enumerate(zip(t.gt_xy, t.gt_marks)):
+        pc = Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2])).poly_coord
+        rr, cc = polygon(pc[:, 0], pc[:, 1], shape=(96, 96))
+        img[rr, cc] = float(k % 2) + rng.normal(0, 0.1, size=(len(rr), 3))
+    img = np.clip(img + rng.normal(0, 0.02, size=img.shape), 0, 1).astype(np.float32)
+    cal = dict(detection_thresh=-0.3, min_area=20.0, max_area=90.0)
+    weights = {"ContrastEnergy": 1.0, "OverlapPriorEnergy": 2.0, "AlignmentPriorEnergy": 0.5, "AreaPriorEnergy": 0.25,
+               "RatioPriorEnergy": 0.75}
+    setup = esc.ContrastMeasureEnergySetup(contrast_type="craciun2", manual_threshold=cal["detection_thresh"])
+    setup.energy_cal = esc.EnergiesCalibration(**cal)
+    comb = ManualHierarchicalEnergyCombinator(weights_dict=weights, indicator_energy="ContrastEnergy", detection_threshold=0.0)
+    params = dict(init_temperature=0.15, target_temperature=0.0, alpha_t=0.998, burn_in=1500, samples_interval=50)
+    rec = record_tape(t, setup, comb, seed=4, rjmcmc_params=params, image=img.astype(np.float64))
+    save_tape("tape_contrast_96.npz", t, rec, "contrast", params,
+              extra=dict(noise=0.15, noise_seed=77 + 7, image=img, contrast_type=np.array("craciun2"),
+                         calibration=np.array(json.dumps(cal)), weights=np.array(json.dumps(weights))))
+
+
 def sorted_rows_np(rows):
     a = np.asarray(rows, dtype=float).reshape(-1, 5)
     return a[np.lexsort(a.T[::-1])] if len(a) else a
@@ -598,7 +726,7 @@ def make_tapes_256():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert", "dota", "host", "tapes256"]
+    what = sys.argv[1:] or ["tapes", "delta", "unet", "pert", "dota", "host", "tapes256", "classics"]
     if "pert" in what:
         make_perturbation_golden()
     if "tapes" in what:
@@ -615,3 +743,7 @@ if __name__ == "__main__":
         make_host_golden()
     if "tapes256" in what:
         make_tapes_256()
+    if "classics" in what:
+        make_classics_golden()
+    if "contrast_tape" in what or "classics" in what:
+        make_contrast_tape()

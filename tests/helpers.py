@@ -43,6 +43,20 @@ def model_for(setup_name: str):
     return setup, comb, energies.build_model_desc(unit, pair, comb)
 
 
+def contrast_model(z):
+    """The contrast energy setup a tape was recorded with (tape_contrast_*.npz: picture, measure, calibration, weights)."""
+    from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps
+    cal, weights = json.loads(str(z["calibration"])), json.loads(str(z["weights"]))
+    setup = energies.ContrastMeasureEnergySetup(contrast_type=str(z["contrast_type"]), manual_threshold=cal["detection_thresh"])
+    setup.energy_cal = cal
+    shape = tuple(int(v) for v in z["shape"])
+    data = ImageWMaps(name="0", shape=shape, image=z["image"], detection_map=None, param_dist_maps=None,
+                      mappings=mappings.default_mappings(), param_names=["size", "ratio", "angle"], labels=None, gt_config=[])
+    unit, pair = setup.make_energies(data)
+    comb = energies.ManualHierarchicalEnergyCombinator(weights, "ContrastEnergy", 0.0)
+    return setup, comb, energies.build_model_desc(unit, pair, comb), energies.classic_image(unit)
+
+
 class Tape:
     """A recorded reference chain (tests/golden/tape_*.npz) turned into replayable proposals."""
 
@@ -61,7 +75,11 @@ class Tape:
         self.p_kernels = z["p_kernels"]
         self.intensity = float(z["intensity"])
         self.E0 = float(z["E0"])
-        self.setup, self.comb, self.model = model_for(self.setup_name)
+        self.image = None                  # the prepared picture of a classic image energy (contrast setup)
+        if self.setup_name == "contrast":
+            self.setup, self.comb, self.model, self.image = contrast_model(z)
+        else:
+            self.setup, self.comb, self.model = model_for(self.setup_name)
         self.kernels = kernels.make_kernels(mappings.default_mappings(), self.intensity,
                                             use_split_merge=len(self.p_kernels) == 10)
         self.proposals = self._proposals()

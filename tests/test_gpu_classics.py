@@ -1,0 +1,278 @@
+"""The contrast energy setup on the GPU (energy_setups/energy_setup_contrast.py:29-105,
+energies/classics.py:100-238): the device's bit-row rasteriser against (i) the values the REFERENCE computed
+(tests/golden/classics_golden.npz), (ii) the CPU oracle's pixel-by-pixel restatement, and chains sampled with a
+classic image energy in the model, step by step against the oracle.
+
+Tolerances: device vs oracle 1e-12 relative (same float64 expressions in the same order; libm vs device sqrt / log in
+the last place); device vs the reference run on the float64 picture 1e-9; vs the reference on the float32 picture 2e-3
+(numpy computes means, variances and the measure in float32 there, see tests/test_classics_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import lockstep_vs_oracle
+from mpp_cnn_rs_object_detection_amd import energies as E
+from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings
+from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps
+from mpp_cnn_rs_object_detection_amd.point_set import EPointsSet
+from mpp_cnn_rs_object_detection_amd.shapes import Rectangle
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "classics_golden.npz"))
+TYPES = ["lafarge", "craciun", "craciun2", "mean", "t-test", "debug"]
+
+
+class _Desc:
+    unit, pair, combinator, gate_term, gate_thr, lin0 = [(E.U_CONST, 0, 1.0, [0.0])], [], 0, -1, 0.0, 0.0
+
+
+def rects():
+    return [Rectangle(int(r[0]), int(r[1]), size=float(r[2]), ratio=float(r[3]), angle=float(r[4])) for r in G["rects"]]
+
+
+def rel(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def term_for(t, image, thresh=0.25):
+    return E.contrast_term("c", image, dilation=2, gap=1 if t != "craciun" else 0, erode=1 if t != "craciun" else 0,
+                           contrast_measure_type=t, rgb=t != "t-test", thresh=thresh, normalize=t == "t-test")
+
+
+def oracle_values(term):
+    H, W = G["image"].shape[:2]
+    o = oracle.Oracle((H, W), np.zeros((H, W), np.float32), None, _Desc())
+    o.set_image(term.image)
+    return np.array([o.unit_value((term.kind, 0, 1.0, term.params), r) for r in G["rects"]])
+
+
+@pytest.mark.parametrize("t", TYPES)
+def test_contrast_values_device(t):
+    term = term_for(t, G["image"] if t != "t-test" else G["noisy_image"])
+    got = E.classic_values(term, rects())
+    want_o, w64, w32 = oracle_values(term), G[f"values64_{t}"], G[f"values32_{t}"]
+    fin = np.isfinite(w64)
+    assert fin.sum() > 80
+    assert np.all(rel(got[fin], want_o[fin]) < 1e-12), np.max(rel(got[fin], want_o[fin]))
+    assert np.all(rel(got[fin], w64[fin]) < (1e-9 if t != "t-test" else 1e-5))
+    assert np.all(rel(got[fin], w32[fin]) < 2e-3)
+    assert np.all(~np.isfinite(got[~fin]) | (np.abs(got[~fin]) > 1e6))
+    # the eroded-away rectangles answer with the measure's default value (classics.py:153-154)
+    fo = G["fill_off_lafarge"]
+    empty = np.nonzero(np.diff(fo) == 0)[0]
+    if t != "craciun" and len(empty):
+        assert np.all(got[empty] == E.CONTRAST_MEASURES[t][2])
+
+
+@pytest.mark.parametrize("rgb", [True, False])
+def test_gradient_values_device(rgb):
+    term = E.gradient_term("g", G["image"], dilation=1, rgb=rgb, thresh=0.1)
+    got, want_o = E.classic_values(term, rects()), oracle_values(term)
+    w32 = G[f"gradient32_{'rgb' if rgb else 'grey'}"]
+    fin = np.isfinite(w32)
+    assert np.all(rel(got[fin], want_o[fin]) < 1e-12)
+    assert np.all(rel(got[fin], w32[fin]) < 1e-6)
+    assert np.all(~np.isfinite(got[~fin]))
+
+
+def setup_and_data(ctype):
+    H, W = G["image"].shape[:2]
+    setup = E.ContrastMeasureEnergySetup(contrast_type=ctype, manual_threshold=-0.05)
+    setup.energy_cal = {"detection_thresh": -0.05, "min_area": 20.0, "max_area": 90.0}
+    rng = np.random.default_rng(3)
+    det = np.clip(0.05 + 0.9 * (np.abs(G["image"].mean(-1) - 0.5) > 0.3) + rng.normal(0, 0.02, (H, W)), 0.01, 1).astype(np.float32)
+    marks = [rng.dirichlet(np.ones(32) * 0.5, size=(H, W)).astype(np.float32) for _ in range(3)]
+    data = ImageWMaps(name="0", shape=(H, W), image=G["image"], detection_map=det, param_dist_maps=marks,
+                      mappings=mappings.default_mappings(), param_names=["size", "ratio", "angle"], labels=None, gt_config=[])
+    return setup, data
+
+
+@pytest.mark.parametrize("ctype", ["craciun2", "gradient"])
+def test_contrast_setup_through_the_facade(ctype):
+    """EPointsSet over ContrastMeasureEnergySetup.make_energies: vectors, energies and Papangelou deltas as the reference
+    computed them for the same 40 points."""
+    setup, data = setup_and_data(ctype)
+    np.random.seed(11)
+    unit, pair = setup.make_energies(data)
+    cfg = G[f"setup_cfg_{ctype}"]
+    pts = [Rectangle(int(r[0]), int(r[1]), size=float(r[2]), ratio=float(r[3]), angle=float(r[4])) for r in cfg]
+    s = EPointsSet(pts, data.shape, unit, pair, image_data=data)
+    vec = s.energy_vectors()
+    want = G[f"setup_vec_{ctype}"]
+    for j, n in enumerate(setup.NAMES):
+        np.testing.assert_allclose(np.asarray(vec[n]), want[:, j], rtol=2e-3, atol=2e-3)
+    comb = E.ManualHierarchicalEnergyCombinator(dict(zip(setup.NAMES, G["setup_weights"])), "ContrastEnergy", 0.0)
+    assert abs(s.total_energy() - float(G[f"setup_total_sum_{ctype}"])) < 2e-3 * len(pts)
+    assert abs(s.total_energy(energy_combinator=comb) - float(G[f"setup_total_comb_{ctype}"])) < 2e-3 * len(pts)
+    pap = s.papangelou_all(energy_combinator=comb, return_energy_delta=True)
+    np.testing.assert_allclose(pap, G[f"setup_papangelou_{ctype}"], rtol=2e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("ctype,spec", [("craciun2", 8), ("lafarge", 1), ("gradient", 8), ("t-test", 8)])
+def test_chain_with_a_classic_energy_against_the_oracle(ctype, spec):
+    """3 000 steps of the sampler under the contrast setup (manual hierarchical combinator, the contrast term gating the
+    priors) on the 96 x 96 scene, lockstep with the oracle: proposals, dE to 1e-9, decisions, final configuration."""
+    setup, data = setup_and_data(ctype)
+    np.random.seed(5)
+    unit, pair = setup.make_energies(data)
+    comb = E.ManualHierarchicalEnergyCombinator(dict(zip(setup.NAMES, [1.0, 2.0, 0.5, 0.25, 0.75])), "ContrastEnergy", 0.0)
+    model = E.build_model_desc(unit, pair, comb)
+    maps = data.mappings
+    kd = kernels.make_kernels(maps, 12.0)
+    o = oracle.Oracle(data.shape, data.detection_map, data.param_dist_maps, model, kd)
+    o.set_image(E.classic_image(unit))
+    xy0 = G["setup_cfg_craciun2"][:12, :2].astype(np.int32)
+    mk0 = G["setup_cfg_craciun2"][:12, 2:]
+    o.set_points(xy0, mk0)
+    T0, alpha = 0.05, 0.999
+    o.set_temperature(T0, alpha, 0.0)
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec)
+    ctx.set_maps(data.detection_map, data.param_dist_maps)
+    ctx.set_image(E.classic_image(unit))
+    ctx.set_model(model, maps)
+    ctx.set_points(0, xy0, mk0)
+    ctx.set_kernels(kd)
+    ctx.set_schedule(T0, alpha, 0.0)
+    e_g, e_o = ctx.total_energy(0), o.total_energy()
+    assert abs(e_g - e_o) < 1e-9 * max(1.0, abs(e_o))
+    ties = lockstep_vs_oracle(ctx, o, 3000, seed=7, chain=0, alpha=alpha, chunk=1000)
+    gxy, gm = ctx.get_points(0)
+    oxy, om = o.get_points()
+    np.testing.assert_array_equal(gxy, oxy)
+    np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
+    assert ties <= 3
+    # untraced production launch (extended kernel, speculative commit) = the traced chain
+    ctx.set_points(0, xy0, mk0)
+    ctx2 = hip_api.MppContext(0, point_capacity=256, spec_waves=spec)
+    ctx2.set_maps(data.detection_map, data.param_dist_maps)
+    ctx2.set_image(E.classic_image(unit))
+    ctx2.set_model(model, maps)
+    ctx2.set_points(0, xy0, mk0)
+    ctx2.set_kernels(kd)
+    ctx2.set_schedule(T0, alpha, 0.0)
+    ctx2.run(3000, seed=7, chain0=0)
+    pxy, pm = ctx2.get_points(0)
+    np.testing.assert_array_equal(pxy, gxy)
+    np.testing.assert_array_equal(pm, gm)
+    ctx.close(); ctx2.close()
+
+
+def test_classic_energy_needs_its_picture_and_the_extended_kernel():
+    setup, data = setup_and_data("craciun2")
+    unit, pair = setup.make_energies(data)
+    model = E.build_model_desc(unit, pair, None)
+    ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=4)
+    ctx.set_maps(data.detection_map, data.param_dist_maps)
+    ctx.set_model(model, data.mappings)
+    ctx.set_kernels(kernels.make_kernels(data.mappings, 1.0))
+    with pytest.raises(hip_api.MppError, match="mpp_set_image"):
+        ctx.total_energy(0)
+    ctx.set_image(E.classic_image(unit))
+    assert np.isfinite(ctx.total_energy(0))
+    with pytest.raises(hip_api.MppError, match="spec_waves 1 or 8"):
+        ctx.run(10, seed=0)
+    with pytest.raises(hip_api.MppError, match="channels"):
+        ctx.set_image(np.zeros(data.shape + (2,), np.float32))
+        ctx.total_energy(0)
+    ctx.close()
+
+
+def test_contrast_threshold_calibration_runs_like_the_reference():
+    """calibrate_detection_threshold of energy_setup_contrast.py:165-205 with the energies from the GPU: the threshold
+    separates the scene's rectangles from random ones (F1 at the chosen threshold well above chance) and is reproducible."""
+    from mpp_cnn_rs_object_detection_amd import calibration as C, synth
+    img, gt_xy, gt_marks = synth.make_scene_image((96, 96), n_rect=40, seed=5)
+    gt = [Rectangle(int(x), int(y), size=float(m[0]), ratio=float(m[1]), angle=float(m[2])) for (x, y), m in zip(gt_xy, gt_marks)]
+    data = ImageWMaps(name="0", shape=(96, 96), image=img, detection_map=None, param_dist_maps=None,
+                      mappings=mappings.default_mappings(), param_names=["size", "ratio", "angle"], labels=None, gt_config=gt)
+    setup = E.ContrastMeasureEnergySetup(contrast_type="craciun2", learn_threshold=True)
+    t1 = C.calibrate_contrast_threshold(setup._make_contrast_energy, [data], np.random.default_rng(0))
+    t2 = C.calibrate_contrast_threshold(setup._make_contrast_energy, [data], np.random.default_rng(0))
+    assert t1 == t2 and np.isfinite(t1) and t1 < 0
+    term = setup._make_contrast_energy(data, detection_thresh=t1)
+    e_gt = E.classic_values(term, gt)
+    assert (e_gt < 0).mean() > 0.6               # most true rectangles fall on the rewarding side of the learned threshold
+
+
+def test_main_with_the_contrast_setup_end_to_end(tmp_path):
+    """``energy_setup: contrast`` through the CLI as a reference user would run it (mpp_model.py:78-81): ``-p train``
+    calibrates (threshold learned from the picture, energy_setup_contrast.py:107-141, :165-205) and builds the manual
+    hierarchical combinator, ``-p infer`` tiles a 300 x 420 picture of rectangles, samples every tile under the contrast
+    energy, merges and scores.  The picture is the only evidence the energy sees; the score maps only steer proposals."""
+    import json
+    import pickle
+    import shutil
+    import subprocess
+    import sys
+    from helpers import REPO
+    from mpp_cnn_rs_object_detection_amd import synth
+    root = tmp_path
+    for d in ("model_configs", "models_storage"):
+        shutil.copytree(os.path.join(REPO, d), root / d)
+    with open(root / "paths_config.json", "w") as f:
+        json.dump({"dataset_path": ["data/"], "model_path": ["models_storage/"]}, f)
+    from matplotlib import pyplot as plt
+    gts = {}
+    for subset, image_id, seed in (("train", 0, 3), ("train", 1, 4), ("val", 7, 5)):
+        H, W = 300, 420
+        img, gt_xy, gt_marks = synth.make_scene_image((H, W), n_rect=260, seed=seed)
+        det, marks = synth.render_maps((H, W), gt_xy, gt_marks)
+        base = root / "data" / "SCENE" / subset
+        for sub in ("images", "annotations", "metadata"):
+            os.makedirs(base / sub, exist_ok=True)
+        plt.imsave(base / "images" / f"{image_id:04}.png", img)
+        b = 2 * gt_marks[:, 0] / (1 + gt_marks[:, 1])
+        with open(base / "annotations" / f"{image_id:04}.pkl", "wb") as f:
+            pickle.dump({"centers": gt_xy.astype(np.int64), "parameters": np.stack([b * gt_marks[:, 1], b, gt_marks[:, 2]], axis=1),
+                         "categories": np.array(["small-vehicle"] * len(gt_xy), dtype=object),
+                         "difficult": np.zeros(len(gt_xy), dtype=np.int64)}, f)
+        with open(base / "metadata" / f"{image_id:04}.json", "w") as f:
+            json.dump({"shape": [H, W], "n_objects": int(len(gt_xy))}, f)
+        for model, payload in (("posvec_dota", {"detection_map": det}),
+                               ("shape_dota", {"output": [np.moveaxis(m, -1, 0)[None] for m in marks],
+                                               "mappings": mappings.default_mappings()})):
+            d = root / "data" / "inference" / "SCENE" / subset / model
+            os.makedirs(d, exist_ok=True)
+            with open(d / f"{image_id:04}_results.pkl", "wb") as f:
+                pickle.dump(payload, f)
+        gts[(subset, image_id)] = gt_xy
+    cfg = {"model_name": "mpp_contrast",
+           "dataset": {"dataset": "SCENE", "position_model": "posvec_dota", "shape_model": "shape_dota", "patch_size": 256},
+           "data_loader": {"batch_size": 2},
+           "energy_setup": "contrast",
+           "energy_setup_params": {"contrast_type": "craciun2", "learn_threshold": True},
+           "manual": {"weights": {"ContrastEnergy": 1.0, "OverlapPriorEnergy": 2.0, "AlignmentPriorEnergy": 0.2,
+                                  "AreaPriorEnergy": 0.2, "RatioPriorEnergy": 0.5},
+                      "indicator_energy": "ContrastEnergy", "threshold": 0.0},
+           "calibration": {"n_images": 2},
+           "inference": {"rjmcmc_params": {"samples_interval": 64, "init_temperature": 0.5, "target_temperature": 0.0,
+                                           "alpha_t": 0.9995, "burn_in": 12000}, "max_score": 4.0}}
+    with open(root / "cfg_contrast.json", "w") as f:
+        json.dump(cfg, f)
+    env = dict(os.environ, PYTHONPATH=REPO)
+    run = lambda proc: subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-p", proc, "-m", "mpp", "-c",
+                                       str(root / "cfg_contrast.json"), "-d", "SCENE", "-o"], cwd=root, env=env,
+                                      capture_output=True, text=True, timeout=900)
+    r = run("train")
+    assert r.returncode == 0, r.stderr[-3000:]
+    store = root / "models_storage" / "mpp" / "mpp_contrast"
+    cal = json.load(open(store / "calibration.json"))
+    assert set(cal) == {"detection_thresh", "min_area", "max_area"} and cal["detection_thresh"] < 0 < cal["min_area"] < cal["max_area"]
+    comb = json.load(open(store / "energy_combination_model.json"))
+    assert comb["type"] == "ManualHierarchicalEnergyCombinator" and comb["indicator_energy"] == "ContrastEnergy"
+    r = run("infer")
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = root / "data" / "inference" / "SCENE" / "val" / "mpp_contrast"
+    with open(out / "0007_results.pkl", "rb") as f:
+        res = pickle.load(f)
+    centers = np.asarray(res["detection_center"], dtype=float)
+    gt_xy = gts[("val", 7)]
+    d = np.sqrt(((centers[:, None, :] - gt_xy[None]) ** 2).sum(-1))
+    recall, precision = (d.min(axis=0) <= 3).mean(), (d.min(axis=1) <= 3).mean()
+    print(f"contrast setup end to end: {len(centers)} detections for {len(gt_xy)} rectangles, recall {recall:.2f}, precision {precision:.2f}")
+    # (the F1-optimal learned threshold rejects the rectangles whose rim is crowded by neighbours: recall is what the
+    # classical energy gives on this dense scene, precision is what the test is about)
+    assert recall >= 0.45 and precision >= 0.9, (recall, precision)

@@ -21,6 +21,8 @@ def make_ctx(t: Tape, spec=1):
         lanes, spec = int(spec[1:]), 1
     ctx = hip_api.MppContext(0, point_capacity=256, spec_waves=spec, spec_lanes=lanes)
     ctx.set_maps(t.det, t.marks)
+    if t.image is not None:
+        ctx.set_image(t.image)
     ctx.set_model(t.model, mappings.default_mappings())
     ctx.set_kernels(t.kernels)
     ctx.set_points(0, t.init_xy, t.init_marks)
@@ -34,6 +36,13 @@ SM_TAPES = ["tape_hrc_96_sm.npz", "tape_log_64_sm.npz"]     # recorded with use_
 @pytest.mark.parametrize("name", SM_TAPES)
 def test_split_merge_tape_replay(name, spec):
     test_tape_replay(name, spec)
+
+
+@pytest.mark.parametrize("spec", [1, 8])
+def test_contrast_setup_tape_replay(spec):
+    """The reference's chain under the contrast energy setup (energy_setup_contrast.py:29-105; picture as float64, so its
+    statistics are float64 arithmetic): same decisions, dE to 2e-6 of the recording and 1e-9 of the oracle."""
+    test_tape_replay("tape_contrast_96.npz", spec)
 
 
 @pytest.mark.parametrize("spec", [1, 4, 8, "L4", "L8"])
@@ -57,6 +66,8 @@ def test_tape_replay(name, spec):
     np.testing.assert_array_equal(got, t.final_by_slots)           # same slots, same order
     # 2. against the float64 oracle, much tighter
     o = oracle.Oracle(t.shape, t.det, t.marks, t.model, t.kernels)
+    if t.image is not None:
+        o.set_image(t.image)
     o.set_points(t.init_xy, t.init_marks)
     o.set_temperature(p["init_temperature"], p["alpha_t"], p["target_temperature"])
     ref = o.replay(t.proposals)
