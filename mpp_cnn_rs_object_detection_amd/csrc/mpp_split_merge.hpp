@@ -113,6 +113,55 @@ __device__ inline int sm_pick(const Chain &c, int ri, int cnt, int j) {
   const int src = m ? __ffsll((long long)m) - 1 : 0;
   return __builtin_amdgcn_readlane(v, src);
 }
+// The same choice when there are more neighbours than the stash area holds (dense, hot configurations; the reference's
+// list has no limit): no list at all.  Candidates are enumerated as in sm_neighbours(), 64 at a time, one per lane; every
+// lane ranks its candidate against ALL neighbours (the enumeration again, one neighbour at a time for the whole wave:
+// broadcast LDS reads), and the candidate of rank j is the one.  O(neighbours^2 / 64): only ever run beyond 32 neighbours.
+__device__ inline int sm_pick_streamed(const Chain &c, int slot0, int x0, int y0, int j) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  const double R = P->kern.split_radius;
+  const int off = (int)ceil(R / P->res);
+  int ci, cj, first = -1;
+  cell_index(c, x0, y0, &ci, &cj);
+  for (int di = -off; di <= off; ++di)
+    for (int dj = -off; dj <= off; ++dj) {
+      const int i = ci + di, jj = cj + dj;
+      if (i < 0 || i >= P->nx || jj < 0 || jj >= P->ny) continue;
+      const int cell = jj + i * P->ny, n_c = (int)L.cell_cnt[cell];
+      for (int e0 = 0; e0 < n_c; e0 += WAVE) {
+        const int e = e0 + c.lane;
+        bool ok = false;
+        int v = 0;
+        if (e < n_c) {
+          v = (int)L.cell_items[(size_t)cell * P->cell_cap + e];
+          const int vxy = L.xy[v], dx = (vxy & 0xffff) - x0, dy = ((vxy >> 16) & 0xffff) - y0;
+          ok = v != slot0 && sqrt((double)(dx * dx + dy * dy)) <= R;
+        }
+        const unsigned long long mk = __ballot(ok);
+        if (!mk) continue;
+        if (first < 0) first = __builtin_amdgcn_readlane(v, __ffsll((long long)mk) - 1);   // (what sm_pick() falls back to)
+        const Rect q = load_rect(L, v);
+        int rank = 0;
+        for (int ei = -off; ei <= off; ++ei)
+          for (int ej = -off; ej <= off; ++ej) {
+            const int i2 = ci + ei, j2 = cj + ej;
+            if (i2 < 0 || i2 >= P->nx || j2 < 0 || j2 >= P->ny) continue;
+            const int cell2 = j2 + i2 * P->ny, n2 = (int)L.cell_cnt[cell2];
+            for (int k = 0; k < n2; ++k) {
+              const int o_slot = (int)L.cell_items[(size_t)cell2 * P->cell_cap + k];
+              const Rect o = load_rect(L, o_slot);
+              const int dx = o.x - x0, dy = o.y - y0;
+              if (o_slot != slot0 && sqrt((double)(dx * dx + dy * dy)) <= R)
+                rank += rect_less(o.x, o.y, o.s, o.r, o.a, q.x, q.y, q.s, q.r, q.a) ? 1 : 0;
+            }
+          }
+        const unsigned long long m = __ballot(ok && rank == j);
+        if (m) return __builtin_amdgcn_readlane(v, __ffsll((long long)m) - 1);
+      }
+    }
+  return first;
+}
 __device__ inline int sm_dense_index(const Chain &c, int n, int slot) {
   int idx = -1;
   for (int i0 = 0; i0 < n; i0 += WAVE) {
@@ -152,7 +201,6 @@ __device__ inline void sm_draw(const Chain &c, Rec &r, int ri, int n, const uint
     return;
   }
   const int cnt = sm_neighbours(c, ri, r.tslot, r.rx, r.ry);
-  if (cnt > STASH) { *err = ERR_CAND_OVERFLOW; r.has_rem = 0; return; }
   if (cnt == 0) {                                     // p0 has no neighbour: empty perturbation (:124-126)
     // ... if the search ran on the state this step will really see: record 0 of a round always does.  A later record of
     // the round may have searched around a point that an earlier step of the round moves: it stays a merge with a
@@ -160,7 +208,8 @@ __device__ inline void sm_draw(const Chain &c, Rec &r, int ri, int n, const uint
     if (ri == 0) r.has_rem = 0;
     return;
   }
-  const int slot1 = sm_pick(c, ri, cnt, (int)mulhi32(w[3], (uint32_t)cnt));
+  const int pick = (int)mulhi32(w[3], (uint32_t)cnt);
+  const int slot1 = cnt <= STASH ? sm_pick(c, ri, cnt, pick) : sm_pick_streamed(c, r.tslot, r.rx, r.ry, pick);
   r.pid = sm_dense_index(c, n, slot1);
 }
 
