@@ -1420,7 +1420,7 @@ __device__ void evaluate(const Chain &c, Rec &r, int ri, int keep, int n, double
 #ifdef MPP_NO_HOIST
       mv = load_map_vals_w(P, c.h.W, c.t, L.edges, add);
 #endif
-      unit_part_mv<EXT>(P, c.t, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr);
+      unit_part_mv<EXT>(P, c.t, mv, add, ag.g, &r.lin_a, &r.gate_a, nullptr, !LANE);
       r.hl = ag.g.hl; r.hw = ag.g.hw; r.ca = ag.g.ca; r.sa = ag.g.sa; r.rad = ag.rad;
       EPROF(6);
     }

@@ -61,34 +61,56 @@ __device__ inline int cl_count(const ClGrid &G, const Bits128 *a) {
   for (int i = 0; i < G.nr; ++i) n += __popcll(a[i].lo) + __popcll(a[i].hi);
   return n;
 }
-// mean and (population) variance of channel ch over the pixels of a mask, row-major
-__device__ inline void cl_stats(const ClGrid &G, const Bits128 *m, const MPP_GLOBAL float *img, int W, int C, int ch,
-                                double *mean, double *var, int *cnt) {
-  double s = 0.0;
-  int n = 0;
+// Sums over the pixels of a mask, row-major, for up to three channels at once: out[ch] = sum x (mu == nullptr) or
+// sum (x - mu[ch])^2.  Pixels are taken 16 at a time: their loads (up to 48) are issued together and then added in pixel
+// order -- one memory latency per 16 pixels instead of one per pixel and channel, the same sums bit for bit.
+#define MPP_CL_BATCH 16
+__device__ inline void cl_flush(const size_t *off, int nb, const MPP_GLOBAL float *img, int C, const double *mu, double *acc) {
+  float v[MPP_CL_BATCH][3];
+#pragma unroll
+  for (int k = 0; k < MPP_CL_BATCH; ++k) {
+    const size_t o = off[k < nb ? k : 0] * (size_t)C;          // (slots beyond nb re-read pixel 0 and are ignored)
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) v[k][ch] = img[o + (ch < C ? ch : 0)];
+  }
+#pragma unroll
+  for (int k = 0; k < MPP_CL_BATCH; ++k)
+    if (k < nb) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const double x = (double)v[k][ch];
+        if (mu) { const double d = x - mu[ch]; acc[ch] += d * d; } else acc[ch] += x;
+      }
+    }
+}
+__device__ inline int cl_sums(const ClGrid &G, const Bits128 *m, const MPP_GLOBAL float *img, int W, int C, const double *mu,
+                              double *acc) {
+  size_t off[MPP_CL_BATCH];
+  int nb = 0, n = 0;
+  acc[0] = acc[1] = acc[2] = 0.0;
   for (int i = 0; i < G.nr; ++i)
     for (int h = 0; h < 2; ++h) {
       unsigned long long w = h ? m[i].hi : m[i].lo;
       while (w) {
         const int j = __ffsll((long long)w) - 1 + 64 * h;
         w &= w - 1;
-        s += (double)img[((size_t)(G.r0 + i) * W + (G.c0 + j)) * C + ch];
+        off[nb++] = (size_t)(G.r0 + i) * W + (G.c0 + j);
         ++n;
+        if (nb == MPP_CL_BATCH) { cl_flush(off, nb, img, C, mu, acc); nb = 0; }
       }
     }
-  const double mu = s / (double)n;
-  double v = 0.0;
-  for (int i = 0; i < G.nr; ++i)
-    for (int h = 0; h < 2; ++h) {
-      unsigned long long w = h ? m[i].hi : m[i].lo;
-      while (w) {
-        const int j = __ffsll((long long)w) - 1 + 64 * h;
-        w &= w - 1;
-        const double d = (double)img[((size_t)(G.r0 + i) * W + (G.c0 + j)) * C + ch] - mu;
-        v += d * d;
-      }
-    }
-  *mean = mu; *var = v / (double)n; *cnt = n;
+  if (nb) cl_flush(off, nb, img, C, mu, acc);
+  return n;
+}
+// mean and (population) variance per channel over the pixels of a mask, two passes as numpy does
+__device__ inline int cl_stats(const ClGrid &G, const Bits128 *m, const MPP_GLOBAL float *img, int W, int C, double *mean,
+                               double *var) {
+  double acc[3];
+  const int n = cl_sums(G, m, img, W, C, nullptr, acc);
+  for (int ch = 0; ch < 3; ++ch) mean[ch] = acc[ch] / (double)n;
+  cl_sums(G, m, img, W, C, mean, acc);
+  for (int ch = 0; ch < 3; ++ch) var[ch] = acc[ch] / (double)n;
+  return n;
 }
 // the contrast measures, classics.py:13-97
 __device__ inline double cl_measure(int type, double mi, double mo, double vi, double vo, int ni, int no) {
@@ -173,14 +195,10 @@ __device__ __noinline__ double classic_contrast(const mpp_unit_term &u, const MP
     cl_dilate(G, H, a, b, dil);
     for (int i = 0; i < G.nr; ++i) a[i] = b_andn(a[i], fill[i]);
   }
+  double mi[3], mo[3], vi[3], vo[3];
+  const int ni = cl_stats(G, fill, img, W, C, mi, vi), no = cl_stats(G, a, img, W, C, mo, vo);
   double val = 0.0;
-  for (int ch = 0; ch < C; ++ch) {
-    double mi, mo, vi, vo;
-    int ni, no;
-    cl_stats(G, fill, img, W, C, ch, &mi, &vi, &ni);
-    cl_stats(G, a, img, W, C, ch, &mo, &vo, &no);
-    val += u.p[5] * cl_measure((int)u.p[0], mi, mo, vi, vo, ni, no);
-  }
+  for (int ch = 0; ch < C; ++ch) val += u.p[5] * cl_measure((int)u.p[0], mi[ch], mo[ch], vi[ch], vo[ch], ni, no);
   return val - u.p[4];
 }
 
@@ -220,15 +238,29 @@ __device__ __noinline__ double classic_gradient(const mpp_unit_term &u, const MP
     if (pr[i] >= 0 && pr[i] < H && pc[i] >= 0 && pc[i] < W) { pr[m] = pr[i]; pc[m] = pc[i]; ++m; }
   const double eps = u.p[1];
   double s = 0.0;
-  for (int i = 0; i < m; ++i) {
-    const int nx = i + 1 < m ? i + 1 : 0, pv = i > 0 ? i - 1 : m - 1;
-    const double t1r = (double)(pr[nx] - pr[i]), t1c = (double)(pc[nx] - pc[i]);
-    const double t2r = (double)(pr[pv] - pr[i]), t2c = (double)(pc[pv] - pc[i]);
-    const double n1r = -t1c, n1c = t1r, n2r = t2c, n2c = -t2r;
-    const double l1 = sqrt(n1r * n1r + n1c * n1c) + eps, l2 = sqrt(n2r * n2r + n2c * n2c) + eps;
-    const double nr = 0.5 * (n1r / l1 + n2r / l2), ncl = 0.5 * (n1c / l1 + n2c / l2);
-    const MPP_GLOBAL float *gp = img + ((size_t)pr[i] * W + pc[i]) * C;
-    for (int k = 0; k < C; ++k) s += (double)gp[k] * ((k & 1) ? ncl : nr);
+  // (8 outline pixels at a time: their up to 48 gradient values are requested together, then used in outline order)
+  for (int i0 = 0; i0 < m; i0 += 8) {
+    float gv[8][6];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k < m ? i0 + k : i0;
+      const MPP_GLOBAL float *gp = img + ((size_t)pr[i] * W + pc[i]) * C;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) gv[k][q] = gp[q < C ? q : 0];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k;
+      if (i >= m) break;
+      const int nx = i + 1 < m ? i + 1 : 0, pv = i > 0 ? i - 1 : m - 1;
+      const double t1r = (double)(pr[nx] - pr[i]), t1c = (double)(pc[nx] - pc[i]);
+      const double t2r = (double)(pr[pv] - pr[i]), t2c = (double)(pc[pv] - pc[i]);
+      const double n1r = -t1c, n1c = t1r, n2r = t2c, n2c = -t2r;
+      const double l1 = sqrt(n1r * n1r + n1c * n1c) + eps, l2 = sqrt(n2r * n2r + n2c * n2c) + eps;
+      const double nr = 0.5 * (n1r / l1 + n2r / l2), ncl = 0.5 * (n1c / l1 + n2c / l2);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) if (q < C) s += (double)gv[k][q] * ((q & 1) ? ncl : nr);
+    }
   }
   const double mean = s / ((double)m * (double)C);
   return -fabs(mean) - u.p[0];

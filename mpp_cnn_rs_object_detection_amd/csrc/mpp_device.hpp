@@ -260,12 +260,24 @@ __device__ __forceinline__ float map_mark(const MapVals &v, int k) {
 
 // one unit energy term of a rectangle.  CL: the classic image energies are compiled in (the chain kernel's extended
 // instantiations and the from-scratch kernels); elsewhere the host never selects a kernel for a model that has them.
+// `one_lane`: the whole wave asks for the same rectangle (the chain's wave mode): lane 0 alone walks the pixels -- the
+// rasteriser keeps its rows in private memory, 64 lanes doing the same would move 64 times the bytes -- and hands the
+// value to the others.
 template <bool CL = false>
 __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const Geo &g, const MapVals &mv,
-                                    const TileRef &t, int H, int W) {
+                                    const TileRef &t, int H, int W, bool one_lane = false) {
   if (CL) {
-    if (u.kind == MPP_U_CONTRAST) return classic_contrast(u, t.img, t.img_c, H, W, g);
-    if (u.kind == MPP_U_GRADIENT) return classic_gradient(u, t.img, t.img_c, H, W, g);
+    if (u.kind == MPP_U_CONTRAST || u.kind == MPP_U_GRADIENT) {
+      double v = 0.0;
+      if (!one_lane || (threadIdx.x & 63) == 0)
+        v = u.kind == MPP_U_CONTRAST ? classic_contrast(u, t.img, t.img_c, H, W, g) : classic_gradient(u, t.img, t.img_c, H, W, g);
+      if (one_lane) {
+        long long b = __double_as_longlong(v);
+        const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+        v = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+      }
+      return v;
+    }
   }
   switch (u.kind) {
     case MPP_U_POSITION: {
@@ -312,19 +324,19 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
 // pixel and the marks, so that their latency overlaps the proposal densities and the trigonometry -- and without)
 template <bool CL = false>
 __device__ inline void unit_part_mv(const DevParams *P, const TileRef &t, const MapVals &mv, const Rect &q, const Geo &g,
-                                    double *lin, int *gate, double *vec_or_null) {
+                                    double *lin, int *gate, double *vec_or_null, bool one_lane = false) {
   const mpp_model &M = P->model;
   const int H = P->H, W = P->W;
   // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
   double vg = 0.0;
   int gt = 1;
   if (M.gate_term >= 0) {
-    vg = unit_value<CL>(M.unit[M.gate_term], q, g, mv, t, H, W);
+    vg = unit_value<CL>(M.unit[M.gate_term], q, g, mv, t, H, W, one_lane);
     gt = (vg <= M.gate_thr) ? 1 : 0;
   }
   double l = M.lin0;
   for (int k = 0; k < M.n_unit; ++k) {
-    double v = (k == M.gate_term) ? vg : unit_value<CL>(M.unit[k], q, g, mv, t, H, W);
+    double v = (k == M.gate_term) ? vg : unit_value<CL>(M.unit[k], q, g, mv, t, H, W, one_lane);
     if (vec_or_null) vec_or_null[k] = v;
     l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
   }
@@ -332,9 +344,9 @@ __device__ inline void unit_part_mv(const DevParams *P, const TileRef &t, const 
 }
 template <bool CL = false>
 __device__ inline void unit_part(const DevParams *P, const TileRef &t, const double *edges, const Rect &q,
-                                 const Geo &g, double *lin, int *gate, double *vec_or_null) {
+                                 const Geo &g, double *lin, int *gate, double *vec_or_null, bool one_lane = false) {
   const MapVals mv = load_map_vals(P, t, edges, q);
-  unit_part_mv<CL>(P, t, mv, q, g, lin, gate, vec_or_null);
+  unit_part_mv<CL>(P, t, mv, q, g, lin, gate, vec_or_null, one_lane);
 }
 __device__ __forceinline__ double pair_part(const DevParams *P, int gate, double r0, double r1) {
   const mpp_model &M = P->model;

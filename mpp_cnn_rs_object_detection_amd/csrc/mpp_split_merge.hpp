@@ -240,7 +240,7 @@ __device__ inline double sm_place(const Chain &c, int slot, bool moving, const R
   ag.rad = geo_radius(ag.g);
   double lin_a, ra0 = 0.0, ra1 = 0.0;
   int gate_a, n_stash = 0;
-  unit_part<true>(P, c.t, L.edges, q, ag.g, &lin_a, &gate_a, nullptr);
+  unit_part<true>(P, c.t, L.edges, q, ag.g, &lin_a, &gate_a, nullptr, true);     // (the whole wave places one rectangle)
   const double dE = eval_delta(c, 0, moving ? slot : -1, true, q, ag, lin_a, gate_a, &ra0, &ra1, &n_stash, true);
   wave_lds_fence();
   int ci, cj;
