@@ -276,3 +276,37 @@ def test_main_with_the_contrast_setup_end_to_end(tmp_path):
     # (the F1-optimal learned threshold rejects the rectangles whose rim is crowded by neighbours: recall is what the
     # classical energy gives on this dense scene, precision is what the test is about)
     assert recall >= 0.45 and precision >= 0.9, (recall, precision)
+
+
+def test_kernel_walks_and_energy_vectors_under_the_contrast_setup():
+    """The callers either side of the sampler with a classic image energy in the model: the kernel random walks of
+    ``perturbation_sampler`` (the extended chain kernel with ``force_accept``), the reference's own property
+    |dE - (E1 - E0)| < 1e-8 for the aggregated perturbations (test/test_perturbation_sampler.py:87-99), and the energy
+    vectors weight learning reads (``mpp_delta_vectors``) against from-scratch vectors of the perturbed configuration."""
+    from mpp_cnn_rs_object_detection_amd.perturbation_sampler import sample_multiple_kernel_perturbations
+    setup, data = setup_and_data("craciun2")
+    cfg = G["setup_cfg_craciun2"][:25]
+    data.gt_config = [Rectangle(int(r[0]), int(r[1]), size=float(r[2]), ratio=float(r[3]), angle=float(r[4])) for r in cfg]
+    np.random.seed(2)
+    unit, pair = setup.make_energies(data)
+    base = EPointsSet(data.gt_config, data.shape, unit, pair, image_data=data)
+    data.gt_config_set = base
+    perts = sample_multiple_kernel_perturbations(data, n_samples=8, rng=np.random.default_rng(0), energy_setup=setup,
+                                                 iter_per_point=2, return_perturbations=True, aggregate_pert=True)
+    e0 = base.total_energy()
+    deltas = base.energy_delta_batch(perts)
+    assert len({len(p.addition) + len(p.removal) for p in perts}) > 1
+    for p, d in zip(perts, deltas):
+        new = base.apply_perturbation(p, inplace=False)
+        assert abs(d - (new.total_energy() - e0)) < 1e-8
+    # the vectors of the points a perturbation touches, after it, equal the from-scratch vectors of the new configuration
+    before, after, mask = base.energy_delta_vectors(perts)
+    n = len(base)
+    for k, p in enumerate(perts[:3]):
+        new = base.apply_perturbation(p, inplace=False)
+        vec = new.energy_vectors()
+        full = np.stack([np.asarray(vec[nm]) for nm in vec], axis=-1)
+        rows = {(u.x, u.y, u.size, u.ratio, u.angle): full[i] for i, u in enumerate(new)}
+        for j, u in enumerate(p.addition):
+            assert mask[k][n + j] == 3
+            np.testing.assert_allclose(after[k][n + j], rows[(u.x, u.y, u.size, u.ratio, u.angle)], rtol=1e-9, atol=1e-9)
