@@ -1102,9 +1102,10 @@ __device__ __forceinline__ MapVals tab_rows_pick(const Chain &c, const TabRows &
 // draw the proposal of a step from its 12 Philox words (the same recipe as the oracle's)
 // w: the step's Philox blocks 0 and 1.  The uniform of the accept test comes from words 6, 7 -- except for the
 // kernels that use all eight words themselves (the two births, split): only they pay for block 2.
+// the kernel of a step and the uniform of its accept test (state-independent)
 template <bool LANE>
-__device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
-                              uint64_t step, uint32_t chain, MapVals *pmv) {
+__device__ __forceinline__ int draw_head(const Chain &c, const uint32_t w[8], Rec &r, uint32_t k0, uint32_t k1,
+                                         uint64_t step, uint32_t chain) {
   const DevParams *P = c.P;
   double uk = u53(w[0], w[1]);
   int k = 0;
@@ -1118,7 +1119,16 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
   } else {
     r.u_acc = u53(w[6], w[7]);
   }
-  *keep = 0;
+  return k;
+}
+// the two birth kernels: everything they draw depends on the step's random words and the score maps only, not on the
+// configuration.  (Kept apart from draw_proposal(): a build that let waves draw their NEXT birth while they wait for the
+// slowest wave of the round lost 6 % -- a waiting wave costs its SIMD nothing, a drawing one competes with the straggler
+// it shares the SIMD with -- but the split itself gained 1.4 % on one tile and 3.2 % with 4 096 chains; a real call
+// (noinline) costs a third of the speed.  DESIGN.md 6.)
+template <bool LANE>
+__device__ void draw_birth(const Chain &c, const uint32_t w[8], int k, Rec &r, int *keep, MapVals *pmv) {
+  const DevParams *P = c.P;
   if (k == MPP_K_UBIRTH) {
     r.has_add = 1;
     r.ax = (int)mulhi32(w[3], (uint32_t)c.h.H); r.ay = (int)mulhi32(w[4], (uint32_t)c.h.W);
@@ -1228,6 +1238,14 @@ __device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r
     DBPROF(15);
     return;
   }
+}
+template <bool LANE>
+__device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
+                              uint64_t step, uint32_t chain, MapVals *pmv) {
+  const DevParams *P = c.P;
+  const int k = draw_head<LANE>(c, w, r, k0, k1, step, chain);
+  *keep = 0;
+  if (k == MPP_K_UBIRTH || k == MPP_K_DBIRTH) { draw_birth<LANE>(c, w, k, r, keep, pmv); return; }
   if (n == 0) return;
   r.tidx = (int)mulhi32(w[2], (uint32_t)n);
   r.tslot = c.L.order[r.tidx];
