@@ -622,9 +622,6 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
         MPP_PAIR_P(0, f0, true, resc0 = true);
         MPP_PAIR_P(1, f1, true, resc1 = true);
       }
-#ifdef MPP_EXP_NORESCAN      /* timing experiment only: how much do the re-reductions cost? (wrong chain) */
-      resc0 = resc1 = false;
-#endif
       // ---- a neighbour lost the point that carried its extremum (its alignment minimum: 0.12 times per step; its
       // overlap maximum: rarely, often in crowded scenes) and the added point does not take over: re-reduce it over its
       // own 3x3 cells.  Done in one lane (rescan_lane, what the generic instantiation does) this walk -- nine cells,
@@ -828,18 +825,6 @@ __device__ double row_prob(const Chain &c, int k, int x, int y, int cls, bool dr
 #pragma unroll
   for (int i = 0; i < 8; ++i) { float4 q = row[i]; v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w; }
   double tot = 0.0;
-#ifdef MPP_NO_CUMSUM
-  if (draw) {
-#pragma unroll
-    for (int i = 0; i < MPP_NCLASS; ++i) tot += (double)v[i];
-    double acc = 0.0, thr = u * tot;
-    int d = 0;
-#pragma unroll
-    for (int i = 0; i < MPP_NCLASS; ++i) { acc += (double)v[i]; d += (acc <= thr) ? 1 : 0; }
-    cls = d < MPP_NCLASS ? d : MPP_NCLASS - 1;
-    *drawn = cls;
-  } else
-#endif
   if (draw) {
     // the running sums ARE the partial sums of the total (same order, same roundings): one dependent chain of 32
     // additions instead of two, the counts afterwards are independent compares
@@ -1137,15 +1122,6 @@ __device__ void draw_birth(const Chain &c, const uint32_t w[8], int k, Rec &r, i
     r.aa = P->maps.vmin[2] + (P->maps.vmax[2] - P->maps.vmin[2]) * u32d(w[7]);
     return;
   }
-#ifdef MPP_EXP_CHEAPDB         /* timing experiment only: a data-driven birth that costs what a uniform one does (wrong chain) */
-  if (k == MPP_K_DBIRTH) {
-    r.has_add = 1;
-    r.ax = (int)mulhi32(w[3], (uint32_t)c.h.H); r.ay = (int)mulhi32(w[4], (uint32_t)c.h.W);
-    r.as = c.L.edges[(int)mulhi32(w[5], 32u)]; r.ar = c.L.edges[MPP_NCLASS + (int)mulhi32(w[6], 32u)]; r.aa = c.L.edges[2 * MPP_NCLASS + (int)mulhi32(w[7], 32u)];
-    r.qf = 1.0; *keep = KEEP_QF;
-    return;
-  }
-#endif
   if (k == MPP_K_DBIRTH) {
     r.has_add = 1;
 #ifdef MPP_PROFILE

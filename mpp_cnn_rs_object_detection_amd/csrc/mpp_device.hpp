@@ -292,9 +292,6 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
       }
       // the three sigmoids are independent chains: keep them side by side
       double p0 = (double)mv.m0, p1 = (double)mv.m1, p2 = (double)mv.m2;
-#ifdef MPP_EXP_NOEXP      /* timing experiment only: what would a table of the remapped marks save? (wrong chain) */
-      { double f0 = -(p0 * u.p[0] + u.p[3]), f1 = -(p1 * u.p[1] + u.p[4]), f2 = -(p2 * u.p[2] + u.p[5]); return (f0 + f1 + f2) / 3.0; }
-#endif
       double e0 = exp(-(p0 * u.p[0] + u.p[3])), e1 = exp(-(p1 * u.p[1] + u.p[4])), e2 = exp(-(p2 * u.p[2] + u.p[5]));
       double acc = 0.0;
       acc += -2.0 * (1.0 / (1.0 + e0)) + 1.0;
