@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../../mpp_cnn_rs_object_detection_amd"
 tmp=$(mktemp -d)
 for f in csrc/*.hip; do
   extra=""
-  if [ "$(basename $f)" = mpp_sampler.hip ]; then extra="-mllvm -disable-machine-licm -mllvm -unroll-threshold=600"; fi
+  if [ "$(basename $f)" = mpp_sampler.hip ]; then extra="-mllvm -disable-machine-licm -mllvm -unroll-threshold=600 -mllvm -unroll-runtime"; fi
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -fvisibility=hidden -std=c++17 $extra "$@" -c $f -o $tmp/$(basename $f .hip).o &
 done
 wait
