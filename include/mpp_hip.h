@@ -137,7 +137,7 @@ int mpp_synchronize(mpp_ctx *ctx);
  * tile t % n_tiles; "remap_table" (-1 auto, default; 0 never; 1 always): chains of a model with the
  * MPP_U_SHAPE_REMAP term read the remapped mark probabilities from [H][W][32] float64 tables built once per mpp_set_maps (as
  * the reference does, energy_setup_legacy.py:142-147) instead of evaluating three sigmoids per proposal -- the same values bit
- * for bit; auto: while the tables fit 16 GB; reading it back tells whether they are in use; "force_accept": apply every proposal without the Metropolis test (the kernel random
+ * for bit; auto: while the tables fit 2 GB (a few tiles sampled long; for hundreds of tiles building them costs more than they save); reading it back tells whether they are in use; "force_accept": apply every proposal without the Metropolis test (the kernel random
  * walks of models/mpp/perturbation_sampler.py:152-169); "scratch_grid_min_points" (default 256; 0 = never): configurations of
  * at least that many points get a candidate grid (PointsSet.get_potential_neighbors, point_set.py:111-145) for
  * mpp_total_energy / mpp_delta_batch / mpp_delta_vectors / mpp_papangelou instead of a scan of all points.  Read-only: "n_chains", "lds_bytes", and the spatial-hash

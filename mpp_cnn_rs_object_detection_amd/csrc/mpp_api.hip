@@ -79,7 +79,10 @@ struct mpp_ctx {
   double *remap[3] = {nullptr, nullptr, nullptr};   // tables of the remapped marks (chains only), see ensure_remap_tables
   bool remap_dirty = true;
   int remap_mode = -1;               // option "remap_table": -1 auto (when the tables fit remap_budget), 0 never, 1 always
-  size_t remap_budget = (size_t)16 << 30;
+  // 2 GB: a handful of tiles sampled for many steps (BASELINE configs 2 and 3: 0.2 GB per 512-px tile).  With the 256 tiles
+  // of a 4096-px image the tables would be 12.9 GB: 3.7 ms less kernel time (5 %) for >= 6 ms of building them and a 13 GB
+  // hipMalloc whose cost varies between 0 and 1.4 s (profiles/tools/probe_remap_cost.py) -- not worth it.
+  size_t remap_budget = (size_t)2 << 30;
   int auto_grow = 1, grow_events = 0; // capacity overflow -> raise the capacity and continue (see run_chain)
   std::vector<double> intensity;
   std::vector<uint64_t> key_seed;    // per-chain Philox key / chain id (mpp_set_chain_keys); empty: the launch's seed, chain0 + tile
@@ -838,7 +841,7 @@ static size_t chain_lds_total(mpp_ctx *c, int cap, int cell_cap) {
 // (energy_setup_legacy.py:142-147); so do chains here: [H][W][32] float64 per mark, holding exactly the summands the
 // inline code forms (same expression, same device exp: the chain is byte-identical with and without the tables).  Only
 // for models whose sole use of the mark maps is that term, only for contexts that run chains (the from-scratch energies of
-// EPointsSet evaluate a few thousand points: inline), and only while 3 x 8 B x 32 per pixel fits the budget (16 GB).
+// EPointsSet evaluate a few thousand points: inline), and only while 3 x 8 B x 32 per pixel fits the budget (2 GB).
 static int ensure_remap_tables(mpp_ctx *c) {
   if (!c->remap_dirty) return 0;
   c->remap_dirty = false;
