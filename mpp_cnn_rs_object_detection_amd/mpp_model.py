@@ -12,6 +12,8 @@ this build; ``train`` supports the ``manual`` mode, which is what ``mpp_hrcM`` u
 """
 from __future__ import annotations
 
+import functools
+import gc
 import json
 import logging
 import os
@@ -104,6 +106,23 @@ class _EpochLoader:
 
     def __iter__(self):
         return iter(self.data.batches(self.batch_size))
+
+
+def _gc_paused(fn):
+    """Run ``fn`` with Python's cyclic garbage collector paused.  An image makes thousands of small acyclic objects
+    (rectangles, tuples); every few images that trips a full collection, which walks every long-lived object of the process
+    (the torch modules of the U-Nets among them) and takes 45-60 ms -- half of what a 4096 x 4096 image costs after its
+    chains (profiles/tools/probe_take.py).  Reference counting still frees everything an image makes."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            if was:
+                gc.enable()
+    return wrapped
 
 
 class MPPModel:
@@ -262,6 +281,7 @@ class MPPModel:
                                   for m in region.param_dist_maps]
         return region
 
+    @_gc_paused
     def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1, region_data: ImageWMaps = None):
         """Tile, sample, merge and score one image.  Returns (detections, scores): an ``EPointsSet`` for one rank,
         the list of merged ``Rectangle``s on every rank of a multi-GPU run (all ranks return the same).
@@ -367,6 +387,7 @@ class MPPModel:
     #: (one workgroup per tile: a launch wants at least the 256 CUs' worth), each with the seed and chain id of its image
     TILES_PER_LAUNCH = 256
 
+    @_gc_paused
     def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None):
         """``infer_image`` for several images at once on one GPU: ALL their tiles in ONE launch (the reference samples
         image after image, `mpp_model.py:220-262`; a DOTA image has 4 - 40 tiles, a launch per image leaves most of the
