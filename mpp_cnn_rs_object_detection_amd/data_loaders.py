@@ -120,7 +120,7 @@ def distance_merge(xy: np.ndarray, scores: np.ndarray, distance: float) -> np.nd
     xy = np.asarray(xy, dtype=float).reshape(-1, 2)
     balls = cKDTree(xy).query_ball_point(xy, r=float(distance))
     for i in range(n):
-        if removed[i]:
+        if removed[i] or len(balls[i]) == 1:           # (alone within `distance`: it is its own best, nothing to remove)
             continue
         near = np.array(sorted(j for j in balls[i] if not removed[j]), dtype=np.int64)
         if len(near) == 0:
