@@ -146,9 +146,13 @@ def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], ori
     merged: List[Rectangle] = []
     for patch, result in zip(patches, results):
         ax, ay = patch.crop_data["tl_anchor"]
+        ax, ay = int(ax), int(ay)
         for r in result:
-            q = copy(r)
-            q.x, q.y = int(q.x + ax), int(q.y + ay)
+            if type(r) is Rectangle:                  # (copy.copy costs four times the constructor)
+                q = Rectangle(int(r.x) + ax, int(r.y) + ay, size=r.size, ratio=r.ratio, angle=r.angle)
+            else:
+                q = copy(r)
+                q.x, q.y = int(q.x + ax), int(q.y + ay)
             merged.append(q)
     agg = EPointsSet(merged, original_image.shape, unit, pair, image_data=original_image, device=device,
                      point_capacity=max(1024, len(merged) + 64))
