@@ -482,7 +482,7 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
 
   DPROF(0); DCOUNT(9, M); DCOUNT(11, 1);
   double de_acc = 0.0, ra[2] = {0.0, 0.0};     // per-lane partials, combined after the loop
-  bool any_changed = false, any_a = false;
+  bool any_changed = false, any_a = false, nonfinite = false;
   int stash_n = 0;
   for (int base = 0; base < M; base += WAVE) {
     int my_base = my_cell * c.h.cell_cap, my_e = ce;
@@ -510,6 +510,9 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
     if (active) {
       gu = load_geo(L, u);
       oldv[0] = L.red0[u]; oldv[1] = L.red1[u];
+      // (generic instantiation only -- the shipped setups have no way to an infinite energy: a neighbour whose own energy
+      // is not finite makes the reference's E(after) - E(before) over the neighbourhood inf - inf = NaN, see below)
+      if (!FAST) { const double lu = L.lin[u]; nonfinite = nonfinite || !(lu - lu == 0.0); }
       if (has_rem) { int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
       if (has_add) { int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
     }
@@ -809,6 +812,10 @@ __device__ double eval_delta(const Chain &c, int ri, int rem, bool has_add, cons
   double dE = sum_de;
   if (has_add) dE += finish_energy_c(c, lin_a + pair_part_c(c, gate_a, ra0, ra1));
   if (has_rem) dE -= finish_energy_c(c, L.lin[rem] + pair_part_c(c, (int)L.gate[rem], L.red0[rem], L.red1[rem]));
+  // The reference subtracts two sums over ALL points of the 3 x 3 cells around the change (energy_graph.py:139-225); with
+  // a point of infinite energy among them (the `craciun` contrast measure on a one-pixel mask) that is inf - inf = NaN
+  // and the step is rejected, whatever the terms that change sum to.
+  if (!FAST) { if (__ballot(nonfinite)) dE = nan(""); }
   DPROF(4);
   return dE;
 }

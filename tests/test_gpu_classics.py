@@ -111,11 +111,11 @@ def test_contrast_setup_through_the_facade(ctype):
     np.testing.assert_allclose(pap, G[f"setup_papangelou_{ctype}"], rtol=2e-3, atol=5e-3)
 
 
-# (not "craciun": its measure is +inf for a one-pixel fill -- log of a zero variance --, the chain soon holds points of
-# energy -inf, and then the reference's E(after) - E(before) over a whole neighbourhood is inf - inf = NaN where the kernel's
-# sum over the CHANGED terms stays finite: DESIGN.md 2, "non-finite energies".  Its values are checked above.)
+# ("craciun": its measure is +inf for a one-pixel fill -- log of a zero variance --, the chain soon holds points of energy
+# -inf, and then the reference's E(after) - E(before) over a whole neighbourhood is inf - inf = NaN: the step is rejected.
+# The generic chain kernel reproduces that, DESIGN.md 2 "non-finite energies".)
 @pytest.mark.parametrize("ctype,spec", [("craciun2", 8), ("lafarge", 1), ("gradient", 8), ("t-test", 8), ("mean", 1),
-                                        ("debug", 8)])
+                                        ("debug", 8), ("craciun", 8), ("craciun", 1)])
 def test_chain_with_a_classic_energy_against_the_oracle(ctype, spec):
     """3 000 steps of the sampler under the contrast setup (manual hierarchical combinator, the contrast term gating the
     priors) on the 96 x 96 scene, lockstep with the oracle: proposals, dE to 1e-9, decisions, final configuration."""
