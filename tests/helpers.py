@@ -227,7 +227,9 @@ def lockstep_vs_oracle(ctx, o, total_steps: int, seed: int, chain: int, alpha: f
             oout, native = o.follow(gprops[start:], seed, chain)
             g = gout[start:]
             tol = de_tolerance(gprops[start:], oout["dE"])
-            bad = np.nonzero((g["accepted"] != oout["accepted"]) | (np.abs(g["dE"] - oout["dE"]) > tol))[0]
+            with np.errstate(invalid="ignore"):       # (NaN on both sides -- a non-finite neighbourhood energy -- is agreement)
+                bad = np.nonzero((g["accepted"] != oout["accepted"]) | (np.abs(g["dE"] - oout["dE"]) > tol) |
+                                 (np.isnan(g["dE"]) != np.isnan(oout["dE"])))[0]
             k = int(bad[0]) if len(bad) else len(g)             # steps start .. start+k-1 agree; step start+k is the suspect
             upto = min(k + 1, len(g))
             for f in exact:
