@@ -19,7 +19,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-fvisibi
 # chains on the same box (400: +2.7 % / -1.8 %; 1 200 and 2 500: as 600; -fno-unroll-loops: -10 %; -O2, -Os, the max-ilp and
 # max-memory-clause schedulers: no gain or worse).  -unroll-runtime (loops whose trip count is only known at run time get an
 # unrolled body with a remainder loop): +0.6 % / +0.7 % on top.  Same arithmetic, byte-identical chains.
-EXTRA = {"mpp_sampler.hip": ["-mllvm", "-disable-machine-licm", "-mllvm", "-unroll-threshold=600", "-mllvm", "-unroll-runtime"]}
+_CHAIN_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-unroll-threshold=600", "-mllvm", "-unroll-runtime"]
+EXTRA = {"mpp_sampler.hip": _CHAIN_FLAGS, "mpp_deep.hip": _CHAIN_FLAGS}
 
 
 def sources():

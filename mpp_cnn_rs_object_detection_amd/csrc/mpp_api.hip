@@ -3,6 +3,7 @@
 // mpp_sampler.hip / mpp_scratch.hip / mpp_maps.hip on the ctx's HIP stream.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -15,6 +16,12 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
                                        const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
                                        long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
+extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax);
+extern "C" size_t mpp_deep_static_lds_bytes(int waves);
+extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
+                                      const TileRef *tiles, int tile0, const long long *until, long long trace_base,
+                                      unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
+                                      mpp_proposal *props, int nmax, int fixed_depth, unsigned long long *stats);
 extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -71,6 +78,11 @@ struct mpp_ctx {
   double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
   bool box_dirty = true;
   int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
+  // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
+  // (0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
+  // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
+  int deep = 0, deep_fixed = 0;
+  unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
   double *ps = nullptr, *pr = nullptr, *pa = nullptr, *T = nullptr;
@@ -199,6 +211,7 @@ extern "C" int mpp_destroy(mpp_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   free_tiles(c);
+  if (c->deep_stats) (void)hipFree(c->deep_stats);
   if (c->g_start) (void)hipFree(c->g_start);
   if (c->g_cursor) (void)hipFree(c->g_cursor);
   if (c->g_items) (void)hipFree(c->g_items);
@@ -232,6 +245,12 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     // lane mode: 4 waves, `v` lanes of each evaluate one speculative step each (4*v steps per round); 0 = off
     if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_lanes must be 0, 1, 2, 4, 8 or 16");
     c->lanes = (int)v;
+  } else if (!strcmp(name, "deep")) {
+    if (v != 0 && (v < 8 || v > 512 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..512");
+    c->deep = (int)v;
+  } else if (!strcmp(name, "deep_fixed")) {
+    if (v < 0 || v > 512) return fail(c, -1, "deep_fixed must be in 0..512");
+    c->deep_fixed = (int)v;
   } else if (!strcmp(name, "replicas")) {
     // independent replica chains per tile: mpp_set_maps(n_tiles = M) then creates M*v chains, chain t on the maps
     // of tile t % M (several chains of one tile with different chain ids, or a benchmark's many-tile load)
@@ -263,6 +282,15 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!c || !name) return -1;
   if (!strcmp(name, "spec_waves")) return c->spec;
   if (!strcmp(name, "spec_lanes")) return c->lanes;
+  if (!strcmp(name, "deep")) return c->deep;
+  if (!strcmp(name, "deep_fixed")) return c->deep_fixed;
+  if (!strncmp(name, "deep_stat", 9) && name[9] >= '0' && name[9] <= '9') {      // deep_stat0 .. deep_stat15
+    const int i = atoi(name + 9);
+    unsigned long long v[16] = {0};
+    if (i > 15) return -1;
+    if (c->deep_stats && hipMemcpy(v, c->deep_stats, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v[i];
+  }
   if (!strcmp(name, "point_capacity")) return c->cap;
   if (!strcmp(name, "replicas")) return c->replicas;
   if (!strcmp(name, "n_chains")) return c->n_tiles;
@@ -890,6 +918,23 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   c->hp.rowbase_lds = (c->H <= 1024 && (c->lanes > 0 || c->spec > 1)) ? 1 : 0;
   if ((c->hp.n_kernels > MPP_K_SPLIT || has_classic(c->hp.model)) && !(c->lanes == 0 && (c->spec == 1 || c->spec == 8)))
     return fail(c, -1, "the split / merge kernels and the classic image energies are built for spec_waves 1 or 8 with spec_lanes 0");
+  // deep rounds: chains of the shipped energy setups drawn from Philox (no tape, no split / merge, no classic image energy)
+  int deep_nmax = 0;
+  {
+    const mpp_model &M = c->hp.model;
+    const bool fast = M.n_pair == 2 && M.pair[0].kind == MPP_P_OVERLAP && M.pair[0].reduce == MPP_REDUCE_MAX &&
+                      M.pair[1].kind == MPP_P_ALIGN && M.pair[1].reduce == MPP_REDUCE_MIN;
+    if (c->deep > 0 && c->lanes == 0 && c->spec <= 8 && !d_tape && fast && c->hp.n_kernels <= MPP_K_SPLIT &&
+        !has_classic(M) && !c->hp.force_accept) {
+      deep_nmax = c->deep < 64 * c->spec ? c->deep : 64 * c->spec;
+      if (deep_nmax < c->spec) deep_nmax = c->spec;
+      if (c->H <= 1024) c->hp.rowbase_lds = 1;
+      if (!c->deep_stats) {
+        HIPCHK(c, hipMalloc((void **)&c->deep_stats, 16 * sizeof(unsigned long long)));
+      }
+      HIPCHK(c, hipMemsetAsync(c->deep_stats, 0, 16 * sizeof(unsigned long long), c->stream));
+    }
+  }
   mpp_launch_set_until(c->stream, c->d_tiles, tile0, grid, (long long)n_steps, c->until);
   HIPCHK(c, hipGetLastError());
   long long trace_base = 0;
@@ -904,11 +949,25 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   const int occ = (grid >= 1024) ? 2 : 1;
   for (;;) {
     size_t lds = chain_lds(c, c->cap, c->cell_cap);
-    if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
+    // deep rounds need room for their step reports next to the chain state: halve the round until it fits, or do without
+    int nmax = deep_nmax;
+    const int ncell_ = c->hp.nx * c->hp.ny, rb_ = c->hp.rowbase_lds ? c->H + 1 : 0;
+    while (nmax >= c->spec && nmax > 0 &&
+           mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax) + mpp_deep_static_lds_bytes(c->spec) > MPP_LDS_LIMIT)
+      nmax /= 2;
+    if (nmax < c->spec || nmax < 8) nmax = 0;
+    if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax);
+    else if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
                   lds, MPP_LDS_LIMIT);
     c->hp.cap = c->cap; c->hp.cell_cap = c->cell_cap;
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    if (nmax > 0) {
+      int fixed = c->deep_fixed > nmax ? nmax : c->deep_fixed;
+      if (fixed > 0) { fixed = fixed / c->spec * c->spec; if (fixed < c->spec) fixed = c->spec; }
+      HIPCHK(c, mpp_launch_deep(c->stream, c->spec, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed, chain0,
+                                trace_tile, d_out, d_props, nmax, fixed, c->deep_stats));
+    } else
     HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed,
                                chain0, d_tape, trace_tile, d_out, d_props));
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));

@@ -932,6 +932,9 @@ __device__ double wrap_mark(const DevParams *P, int k, double v) {
 // SIMDs of the CU).  The arithmetic (and its order) is the one of the wave-cooperative functions above,
 // so both modes produce byte-identical chains.
 // =====================================================================================================
+// STASH_ON = false (the deep-round kernel, mpp_deep.hip): nothing is stashed -- a step that commits is evaluated a second
+// time with `apply` -- only the number of neighbours that change is counted.
+template <bool STASH_ON = true>
 __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add, const Rect &ar, const Geo2 &ag,
                                   double lin_a, int gate_a, double *ra0_out, double *ra1_out, int *n_stash, bool apply) {
   const DevParams *P = c.P;
@@ -998,7 +1001,7 @@ __device__ double eval_delta_lane(const Chain &c, int ri, int rem, bool has_add,
           sum_de += finish_energy_c(c, lin + pair_part_c(c, gt, newv[0], newv[1])) -
                     finish_energy_c(c, lin + pair_part_c(c, gt, oldv[0], oldv[1]));
           if (apply) { L.red0[u] = newv[0]; L.red1[u] = newv[1]; }
-          else if (stash_n < STASH) {
+          else if (STASH_ON && stash_n < STASH) {
             L.stash_slot[ri * STASH + stash_n] = (unsigned short)u;
             L.stash_v0[ri * STASH + stash_n] = newv[0];
             L.stash_v1[ri * STASH + stash_n] = newv[1];

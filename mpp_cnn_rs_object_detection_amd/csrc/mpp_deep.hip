@@ -1,0 +1,968 @@
+// mpp_deep.hip -- the "deep round" chain kernel: every LANE evaluates one speculative step.
+//
+// Same chain, same bits as mpp_chain_kernel (mpp_sampler.hip) -- the reference's loop rjmcmc.py:83-164 with the
+// proposals drawn from Philox by step index -- organised for what the chain actually does after its first few thousand
+// steps: of the ~25 % of proposals the Metropolis test accepts, four out of five re-write a point with the very values it
+// already has (a data-driven transform that draws the class the mark sits in, a translation onto the same pixel), and
+// only 2-5 % of all steps change the configuration.  A round of 8 steps, one wave each, is then almost always all
+// rejects -- and costs a wave's latency per step.  Here a round is up to 64 * WAVES steps:
+//   A  the kernel TYPE of each of the round's steps is a function of its Philox words alone; the steps are counting-
+//      sorted by type across the workgroup so that the lanes of one wave run (mostly) the same kernel and do not
+//      serialise on the draw;
+//   B  every active lane draws and evaluates its step on its own against the round's start state (the lane forms of
+//      draw_proposal / evaluate: the arithmetic, and its order, are those of the wave forms), decides it, and reports
+//      (valid, changes-the-state, slot, positions) in 12 bytes of LDS;
+//   C  every wave takes the same commit decision from those reports: steps commit in order; a committed change
+//      invalidates the later steps that could have seen it (same slot, same cell, within 2 * max_inter) and the round ends
+//      at the first invalid step; an accepted step that writes the bits that are already there changes nothing and ends
+//      nothing;
+//   D  the few lanes whose step commits with a change evaluate it a second time, writing the cached reductions of the
+//      neighbours directly (no stash), and after a barrier move the point between cell lists and re-write its slot.
+// The depth of a round follows the number of steps the last rounds committed.  Temperatures are a function of the step
+// index alone: a ring in LDS holds those of the next steps, extended by as many entries as a round commits.
+#include <cstdlib>
+
+#include "mpp_chain.hpp"
+
+#define DEEP_NMAX_LIMIT 512
+#define DEEP_CLIST 192         // candidate neighbours a wave collects before it evaluates them (>= 64: one cell's entries fit)
+#ifdef MPP_DEEP_PROF
+// diagnostic build only (profiles/tools/build_deep_prof.sh): cycles of wave 0 per phase of a round, summed over the launch,
+// in stats[4..15]
+#define DPH_T0() unsigned long long dph_t_ = clock64()
+#define DPH(i) do { const unsigned long long n_ = clock64(); dph_[i] += n_ - dph_t_; dph_t_ = n_; } while (0)
+#else
+#define DPH_T0()
+#define DPH(i)
+#endif
+// info word 0: bits 0..15 slot, then flags
+#define DI_VALID (1 << 16)
+#define DI_CHG (1 << 17)
+#define DI_HR (1 << 18)
+#define DI_HA (1 << 19)
+#define DI_BAD (1 << 20)     // the proposal could not be formed (reported when the commit reaches it)
+#define DI_ACC (1 << 21)
+
+struct DeepLds {
+  int *info;                   // [nmax][3]: flags | slot, removed xy, added xy -- indexed by the step's offset in the round
+  uint4 *pw;                   // [nmax] Philox block 0 of the steps, in sorted order
+  unsigned short *poff;        // [nmax] sorted position -> offset of the step in the round
+  unsigned short *tcnt;        // [WAVES][16] steps of each kernel type per wave
+  double *tring;               // [2 * nmax] temperature of step (offset & mask)
+  unsigned long long *racc;    // [WAVES][2][64] per step of a wave: max of the overlaps / min of the alignments with the added point
+  unsigned int *clist;         // [WAVES][DEEP_CLIST] (step << 16 | slot): the neighbours in range of a wave's steps, in order
+};
+__host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
+  return (size_t)nmax * 16 + (size_t)2 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 12 +
+         (size_t)nmax * 2 + (size_t)waves * 16 * 2 + 64;
+}
+__host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
+  return (lds_bytes(cap, ncell, cell_cap, 0, rowbase_n, waves) + 15) & ~(size_t)15;
+}
+__device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
+  DeepLds D;
+  D.pw = (uint4 *)base; base += (size_t)nmax * 16;
+  D.tring = (double *)base; base += (size_t)2 * nmax * 8;
+  D.racc = (unsigned long long *)base; base += (size_t)waves * 2 * 64 * 8;
+  D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
+  D.info = (int *)base; base += (size_t)nmax * 12;
+  D.poff = (unsigned short *)base; base += (size_t)nmax * 2;
+  D.tcnt = (unsigned short *)base;
+  return D;
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ const DevParams *deep_stage_params(const DevParams &Pv, int nthr) {
+  if constexpr (IN_LDS) {
+    __shared__ DevParams s_P;
+    const int *src = (const int *)&Pv;
+    int *dst = (int *)&s_P;
+    for (int i = threadIdx.x; i < (int)(sizeof(DevParams) / 4); i += nthr) dst[i] = src[i];
+    __syncthreads();
+    return &s_P;
+  } else {
+    return &Pv;
+  }
+}
+
+// ---- state mutation by ONE lane (energy_point_set.py:118-154); two steps that commit in the same round touch different
+// cells and slots
+__device__ __forceinline__ void cell_remove_1(const Chain &c, int cell, int slot) {
+  const Lds &L = c.L;
+  const int cnt = L.cell_cnt[cell];
+  unsigned short *it = L.cell_items + (size_t)cell * c.h.cell_cap;
+  int idx = -1;
+  for (int i = 0; i < cnt; ++i) if (idx < 0 && it[i] == slot) idx = i;
+  if (idx >= 0) {
+    it[idx] = it[cnt - 1];
+    L.cell_cnt[cell] = (unsigned short)(cnt - 1);
+  }
+}
+__device__ __forceinline__ void cell_insert_1(const Chain &c, int cell, int slot) {
+  const Lds &L = c.L;
+  const int cnt = L.cell_cnt[cell];          // (room was checked when the step was chosen)
+  L.cell_items[(size_t)cell * c.h.cell_cap + cnt] = (unsigned short)slot;
+  L.cell_cnt[cell] = (unsigned short)(cnt + 1);
+}
+__device__ __forceinline__ void write_slot_1(const Chain &c, int slot, const Rec &q) {
+  const Lds &L = c.L;
+  L.xy[slot] = (q.ax & 0xffff) | (q.ay << 16);
+  L.s[slot] = q.as; L.r[slot] = q.ar; L.a[slot] = q.aa;
+  L.ca[slot] = q.ca; L.sa[slot] = q.sa; L.hl[slot] = q.hl; L.hw[slot] = q.hw; L.rad[slot] = q.rad;
+  L.lin[slot] = q.lin_a; L.gate[slot] = (unsigned char)q.gate_a; L.red0[slot] = q.ra0; L.red1[slot] = q.ra1;
+}
+
+// evaluate() of mpp_chain.hpp in its lane form, in two halves around the ONE call of eval_delta_lane the kernel has (the
+// step's evaluation and, for a step that commits, the second pass that writes the neighbours' reductions go through the
+// same call site: with two, the inliner leaves a real call behind and the chain state lives in scratch memory)
+__device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool tracing, const MapVals &pmv) {
+  const DevParams *P = c.P;
+  const Lds &L = c.L;
+  MapVals mv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
+  if (keep & KEEP_MV) mv = pmv;
+  else if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
+  proposal_densities(c, r, tracing, keep, false);
+  r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
+  r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
+  if (r.has_add) {
+    Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
+    Geo g;
+    g.x = add.x; g.y = add.y; g.hl = g.hw = g.ca = g.sa = 0.0;
+    double rad = 0.0;
+    if (keep & KEEP_SIZE) { g.hl = L.hl[r.tslot]; g.hw = L.hw[r.tslot]; rad = L.rad[r.tslot]; }
+    else {
+      double length = (2.0 * add.s) / (1.0 + add.r), width = add.r * length;
+      g.hl = length / 2.0; g.hw = width / 2.0;
+      rad = geo_radius(g);
+    }
+    if (keep & KEEP_TRIG) { g.ca = L.ca[r.tslot]; g.sa = L.sa[r.tslot]; }
+    else if (keep & KEEP_EDGE_ANGLE) { g.ca = L.trig[r.acls]; g.sa = L.trig[MPP_NCLASS + r.acls]; }
+    else { double al = add.a + MPP_PI / 2.0; g.ca = cos(al); g.sa = sin(al); }
+    unit_part_mv<false>(P, c.t, mv, add, g, &r.lin_a, &r.gate_a, nullptr, false);
+    r.hl = g.hl; r.hw = g.hw; r.ca = g.ca; r.sa = g.sa; r.rad = rad;
+  }
+}
+__device__ __forceinline__ void deep_post(const Chain &c, Rec &r, int n, double T, bool tracing) {
+  double fwd, bwd;
+  green_terms(c.P, r, n, c.t.intensity, &fwd, &bwd);
+  // rjmcmc.py:105-113 (one exp instead of three logs, see evaluate())
+  double ratio = (bwd + EPS_GREEN) / (fwd + EPS_GREEN);
+  r.accepted = ((r.u_acc + EPS_GREEN) < exp(-r.dE / T) * ratio) ? 1 : 0;
+  if (tracing) { r.fwd = fwd; r.bwd = bwd; r.log_alpha = (-r.dE / T) + log(bwd + EPS_GREEN) - log(fwd + EPS_GREEN); }
+}
+
+// inclusive prefix sum over the 64 lanes (DPP: shifts within the rows of 16, then the two row broadcasts); EXEC must be full
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
+  return v;
+}
+__device__ __forceinline__ double shfl_d(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffll), lane, WAVE), hi = __shfl((int)(b >> 32), lane, WAVE);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// The neighbours' part of dE for ALL steps a wave evaluates (energy_graph.py:139-225; the arithmetic of eval_delta<FAST>,
+// mpp_chain.hpp, per neighbour, summed in the same order).  Lane i leads step i (`lead`: it has a point to remove and / or a
+// rectangle to add).  One lane walking the 3 x 3 cells around its own step's points is a chain of dependent LDS reads per
+// cell and entry (78 k cycles a round); here the work of all the wave's steps is dealt to all 64 lanes, twice:
+//   1  the (step, cell) pairs -- 18 per step -- go to the lanes, 64 at a time; a lane looks at its cell's entries, four at a
+//      time, and keeps those within the longest interaction range of the removed or the added point; an exclusive prefix
+//      sum puts them into the wave's candidate list in (step, cell, entry) order -- the order eval_delta sums in;
+//   2  the list goes to the lanes, 64 (step, neighbour) pairs at a time: the neighbour's geometry and cached reductions from
+//      LDS, the step's added rectangle from its leader's registers (ds_bpermute); rectangle clips and the re-reduction of a
+//      neighbour that loses its extremum are done by the whole wave, one after the other, as in eval_delta<FAST>; the few
+//      neighbours whose energy changes are added to their step's sum in list order; the reductions of the added point
+//      itself (max / min: order-free) are LDS atomics on the bit patterns.
+// `apply` (wave-uniform): the changed reductions are written to the caches (the second pass of a step that commits).
+// Model: pair 0 = rectangle overlap / max, pair 1 = alignment / min (FAST).
+__device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, bool lead, bool has_rem, bool has_add, int rem,
+                                           int rxy, int axy, double a_s, double a_r, double a_a, double a_hl, double a_hw,
+                                           double a_ca, double a_sa, double a_rad, bool apply, double *sum_out, double *ra0_out,
+                                           double *ra1_out, int *nchg_out) {
+  const Lds &L = c.L;
+  unsigned int *clist = D.clist + (size_t)c.wave * DEEP_CLIST;
+  unsigned long long *racc = D.racc + (size_t)c.wave * 128;
+  const int flags = (lead ? 4 : 0) | (lead && has_rem ? 1 : 0) | (lead && has_add ? 2 : 0);
+  const int maxd2_0 = c.pr0.maxd2, maxd2_1 = c.pr1.maxd2, range2 = maxd2_0 > maxd2_1 ? maxd2_0 : maxd2_1;
+  const double rew = c.pr1.p0 != 0.0 ? 1.0 : 0.0;
+  const unsigned long long below = (1ull << c.lane) - 1ull;
+  const unsigned long long leadm = __ballot(lead);
+  const int nlead = leadm ? 64 - __clzll((long long)leadm) : 0;
+  const int ntasks = 18 * nlead;
+  racc[c.lane] = 0ull; racc[64 + c.lane] = 0ull;
+  wave_lds_fence();
+  double sum = 0.0;
+  int nchg = 0, M = 0, t0 = 0;
+  bool pending = false;
+  int p_cnt = 0, p_base = 0, p_i = 0;
+  unsigned long long p_mask = 0ull;
+  for (;;) {
+    bool final = false;
+    if (__ballot(pending) == 0ull) {
+      if (t0 >= ntasks) final = true;
+      else {
+        // ---- 1: the next 64 (step, cell) pairs
+        const int t = t0 + c.lane;
+        t0 += WAVE;
+        const int i = (t * 3641) >> 16, k = t - 18 * i;            // t / 18, t % 18 (t < 1152)
+        const int sfl = __shfl(flags, i & 63, WAVE), srem = __shfl(rem, i & 63, WAVE), srxy = __shfl(rxy, i & 63, WAVE),
+                  saxy = __shfl(axy, i & 63, WAVE);
+        const bool s_hr = sfl & 1, s_ha = sfl & 2;
+        const int rx = srxy & 0xffff, ry = (srxy >> 16) & 0xffff, ax = saxy & 0xffff, ay = (saxy >> 16) & 0xffff;
+        const int cir = cell_coord(c, rx), cjr = cell_coord(c, ry), cia = cell_coord(c, ax), cja = cell_coord(c, ay);
+        const bool second = k >= 9;
+        const int kk = second ? k - 9 : k, k3 = (kk * 11) >> 5;    // kk / 3 for kk < 9
+        const int ci = (second ? cia : cir) + k3 - 1, cj = (second ? cja : cjr) + (kk - 3 * k3) - 1;
+        bool ok = t < ntasks && (sfl & 4) && (second ? s_ha : s_hr);
+        if (ok && second && s_hr && abs(ci - cir) <= 1 && abs(cj - cjr) <= 1) ok = false;      // already listed
+        ok = ok && ci >= 0 && ci < c.h.nx && cj >= 0 && cj < c.h.ny;
+        const int cell = ok ? cj + ci * c.h.ny : 0;
+        const int cnt = ok ? (int)L.cell_cnt[cell] : 0;
+        const int base = cell * c.h.cell_cap;
+        unsigned long long mask = 0ull;
+        for (int e0 = 0; __ballot(e0 < cnt) != 0ull; e0 += 4) {
+          int u_[4], xy_[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) u_[q] = e0 + q < cnt ? (int)L.cell_items[base + e0 + q] : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xy_[q] = e0 + q < cnt ? L.xy[u_[q]] : 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int ux = xy_[q] & 0xffff, uy = (xy_[q] >> 16) & 0xffff;
+            const int dxr = ux - rx, dyr = uy - ry, dxa = ux - ax, dya = uy - ay;
+            const bool inr = (s_hr && dxr * dxr + dyr * dyr <= range2) || (s_ha && dxa * dxa + dya * dya <= range2);
+            if (e0 + q < cnt && u_[q] != (s_hr ? srem : -1) && inr) mask |= 1ull << (e0 + q);
+          }
+        }
+        p_cnt = __popcll(mask); p_mask = mask; p_base = base; p_i = i;
+        pending = p_cnt > 0;
+      }
+    }
+    bool flush = final;
+    if (!final) {
+      // append the pairs of the waiting lanes, in lane order, as far as the list has room
+      const int c_ = pending ? p_cnt : 0;
+      const int incl = wave_incl_scan(c_);
+      const bool fit = pending && M + incl <= DEEP_CLIST;
+      const unsigned long long fm = __ballot(fit);
+      if (fit) {
+        int pos = M + incl - c_;
+        unsigned long long m = p_mask;
+        while (m) {
+          const int e = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          clist[pos++] = ((unsigned int)p_i << 16) | (unsigned int)L.cell_items[p_base + e];
+        }
+        pending = false;
+      }
+      if (fm) M = __builtin_amdgcn_readlane(M + incl, 63 - __clzll((long long)fm));
+      flush = __ballot(pending) != 0ull;                   // what is left did not fit: evaluate the list first
+    }
+    if (flush && M > 0) {
+      wave_lds_fence();
+      // ---- 2: the list, 64 (step, neighbour) pairs at a time
+      for (int j0 = 0; j0 < M; j0 += WAVE) {
+        const int j = j0 + c.lane;
+        const bool act = j < M;
+        const unsigned int cu = act ? clist[j] : 0u;
+        const int i = (int)(cu >> 16), u = (int)(cu & 0xffffu);
+        const int sfl = __shfl(flags, i, WAVE), srem = __shfl(rem, i, WAVE), saxy = __shfl(axy, i, WAVE);
+        const bool s_hr = act && (sfl & 1), s_ha = act && (sfl & 2);
+        Geo2 ag;
+        ag.g.x = saxy & 0xffff; ag.g.y = (saxy >> 16) & 0xffff;
+        ag.g.hl = shfl_d(a_hl, i); ag.g.hw = shfl_d(a_hw, i); ag.g.ca = shfl_d(a_ca, i); ag.g.sa = shfl_d(a_sa, i);
+        ag.rad = shfl_d(a_rad, i);
+        Geo2 gr, gu;
+        gr.g.x = gr.g.y = 0; gr.g.hl = gr.g.hw = gr.g.ca = gr.g.sa = 0.0; gr.rad = 0.0;
+        gu = gr;
+        double ov0 = 0.0, ov1 = 0.0;
+        if (s_hr) gr = load_geo(L, srem);
+        if (act) { gu = load_geo(L, u); ov0 = L.red0[u]; ov1 = L.red1[u]; }
+        int d2r = 0, d2a = 0;
+        if (s_hr) { const int dx = gu.g.x - gr.g.x, dy = gu.g.y - gr.g.y; d2r = dx * dx + dy * dy; }
+        if (s_ha) { const int dx = gu.g.x - ag.g.x, dy = gu.g.y - ag.g.y; d2a = dx * dx + dy * dy; }
+        // marks of the added rectangle: only the order of two rectangles on the same pixel asks for them
+        const bool tie_a = s_ha && gu.g.x == ag.g.x && gu.g.y == ag.g.y;
+        double sa_s = 0.0, sa_r = 0.0, sa_a = 0.0;
+        if (__ballot(tie_a) != 0ull) { sa_s = shfl_d(a_s, i); sa_r = shfl_d(a_r, i); sa_a = shfl_d(a_a, i); }
+        // -- overlaps first, in uniform control flow: every pair whose circumscribed circles meet is clipped by the wave
+        const bool in_r0 = s_hr && d2r <= maxd2_0 && ov0 != 0.0, in_a0 = s_ha && d2a <= maxd2_0;
+        const double Au = geo_area(gu.g);
+        double ovl_r = 0.0, ovl_a = 0.0;
+#pragma clang loop unroll(disable)
+        for (int which = 0; which < 2; ++which) {
+          const Geo2 gv = which == 0 ? gr : ag;
+          bool need = which == 0 ? in_r0 : in_a0;
+          double mn = 0.0;
+          bool uf = false;
+          if (need) {
+            const double B = geo_area(gv.g), reach = gu.rad + gv.rad, d2 = (double)(which == 0 ? d2r : d2a);
+            mn = Au < B ? Au : B;
+            need = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
+            if (need) {
+              if (which == 0) uf = slot_first(L, u, gu.g, gv.g.x, gv.g.y, L.s[srem], L.r[srem], L.a[srem]);
+              else uf = slot_first(L, u, gu.g, gv.g.x, gv.g.y, sa_s, sa_r, sa_a);
+            }
+          }
+          double val = 0.0;
+          unsigned long long m = __ballot(need);
+          while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            Geo bu, bv;
+            bu.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.y = __builtin_amdgcn_readlane(gu.g.y, src);
+            bu.hl = readlane_d(gu.g.hl, src); bu.hw = readlane_d(gu.g.hw, src);
+            bu.ca = readlane_d(gu.g.ca, src); bu.sa = readlane_d(gu.g.sa, src);
+            bv.x = __builtin_amdgcn_readlane(gv.g.x, src); bv.y = __builtin_amdgcn_readlane(gv.g.y, src);
+            bv.hl = readlane_d(gv.g.hl, src); bv.hw = readlane_d(gv.g.hw, src);
+            bv.ca = readlane_d(gv.g.ca, src); bv.sa = readlane_d(gv.g.sa, src);
+            const bool u_first = __builtin_amdgcn_readlane((int)uf, src) != 0;
+            double ux[4], uy[4], vx[4], vy[4];
+            geo_corners(bu, ux, uy); geo_corners(bv, vx, vy);
+            double sx[4], sy[4], cx[4], cy[4];          // subject = the smaller rectangle in the canonical order
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              sx[q] = u_first ? ux[q] : vx[q]; sy[q] = u_first ? uy[q] : vy[q];
+              cx[q] = u_first ? vx[q] : ux[q]; cy[q] = u_first ? vy[q] : uy[q];
+            }
+            const double area = clip_area_wave(c, sx, sy, cx, cy);
+            if (c.lane == src) val = area / (mn + AREA_EPS);
+          }
+          if (which == 0) ovl_r = val; else ovl_a = val;
+        }
+        // -- the two reductions of the neighbour (MPP_PAIR_P of eval_delta)
+        double nv0 = ov0, nv1 = ov1;
+        bool resc0 = false, resc1 = false;
+        if (act) {
+          {                                                        // pair 0: overlap, max
+            bool carries = false;
+            if (in_r0) carries = ovl_r == ov0;
+            if (in_a0 && ovl_a > 0.0) atomicMax(&racc[i], (unsigned long long)__double_as_longlong(ovl_a));
+            if (carries) { if (in_a0 && ovl_a >= ov0) nv0 = ovl_a; else resc0 = true; }
+            else if (in_a0) nv0 = ov0 > ovl_a ? ov0 : ovl_a;
+          }
+          {                                                        // pair 1: alignment, min
+            const bool in_r1 = s_hr && d2r <= maxd2_1 && ov1 != 0.0, in_a1 = s_ha && d2a <= maxd2_1;
+            bool carries = false;
+            double v_add = 0.0;
+            if (in_r1) carries = (1.0 - fabs(gu.g.ca * gr.g.ca + gu.g.sa * gr.g.sa) - rew) == ov1;
+            if (in_a1) {
+              v_add = 1.0 - fabs(gu.g.ca * ag.g.ca + gu.g.sa * ag.g.sa) - rew;
+              if (v_add < 0.0) atomicMax(&racc[64 + i], (unsigned long long)__double_as_longlong(v_add));
+            }
+            if (carries) { if (in_a1 && v_add <= ov1) nv1 = v_add; else resc1 = true; }
+            else if (in_a1) nv1 = ov1 < v_add ? ov1 : v_add;
+          }
+        }
+        // -- a neighbour lost the point that carried its extremum and the added point does not take over: the wave
+        //    re-reduces it over its own 3 x 3 cells (lane 3k+e on entry e of cell k; fuller cells: 64 entries per turn)
+        unsigned long long rm = __ballot(resc0 || resc1);
+        const int ck = c.lane / 3, ce = c.lane - 3 * ck;
+        while (rm) {
+          const int src = __ffsll((long long)rm) - 1;
+          rm &= rm - 1;
+          const bool need0 = __builtin_amdgcn_readlane((int)resc0, src) != 0, need1 = __builtin_amdgcn_readlane((int)resc1, src) != 0;
+          const int us = __builtin_amdgcn_readlane(u, src), is = __builtin_amdgcn_readlane(i, src);
+          const int rem_s = __builtin_amdgcn_readlane(srem, src);              // (the neighbour lost a removed point: has_rem)
+          const bool ha_s = __builtin_amdgcn_readlane((int)s_ha, src) != 0;
+          Geo2 bu, ba;                                       // the neighbour and its step's added rectangle, wave-uniform
+          bu.g.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.g.y = __builtin_amdgcn_readlane(gu.g.y, src);
+          bu.g.hl = readlane_d(gu.g.hl, src); bu.g.hw = readlane_d(gu.g.hw, src);
+          bu.g.ca = readlane_d(gu.g.ca, src); bu.g.sa = readlane_d(gu.g.sa, src); bu.rad = readlane_d(gu.rad, src);
+          ba.g.x = __builtin_amdgcn_readlane(ag.g.x, src); ba.g.y = __builtin_amdgcn_readlane(ag.g.y, src);
+          ba.g.hl = readlane_d(ag.g.hl, src); ba.g.hw = readlane_d(ag.g.hw, src);
+          ba.g.ca = readlane_d(ag.g.ca, src); ba.g.sa = readlane_d(ag.g.sa, src); ba.rad = readlane_d(ag.rad, src);
+          int uci, ucj;
+          cell_index(c, bu.g.x, bu.g.y, &uci, &ucj);
+          int cell2 = -1;
+          if (ck < 9) {
+            const int ii = uci + ck / 3 - 1, jj = ucj + ck % 3 - 1;
+            if (ii >= 0 && ii < c.h.nx && jj >= 0 && jj < c.h.ny) cell2 = jj + ii * c.h.ny;
+          }
+          const int cnt2 = cell2 >= 0 ? (int)L.cell_cnt[cell2] : 0;
+          const bool direct2 = __ballot(cnt2 > 3) == 0ull;
+          int M2 = WAVE;
+          if (!direct2) {
+            M2 = 0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) M2 += __builtin_amdgcn_readlane(cnt2, 3 * k);
+          }
+          const double Aus = geo_area(bu.g);
+          double acc0 = 0.0, acc1 = 0.0;                     // wave-uniform results
+          for (int base2 = 0; base2 < M2; base2 += WAVE) {
+            int it_base = cell2 * c.h.cell_cap, it_e = ce;
+            bool act2 = ce < cnt2;
+            if (!direct2) {
+              const int jx = base2 + c.lane;
+              int lo = 0, my_lo = 0;
+              it_base = 0;
+#pragma unroll
+              for (int k = 0; k < 9; ++k) {
+                const int cnt_k = __builtin_amdgcn_readlane(cnt2, 3 * k), cell_k = __builtin_amdgcn_readlane(cell2, 3 * k);
+                if (jx >= lo && cnt_k > 0) { my_lo = lo; it_base = cell_k * c.h.cell_cap; }
+                lo += cnt_k;
+              }
+              act2 = jx < M2;
+              it_e = jx - my_lo;
+            }
+            const int w = act2 ? (int)L.cell_items[it_base + it_e] : 0;
+            if (act2 && (w == us || w == rem_s)) act2 = false;
+            int wx = 0, wy = 0, d2w = 0;
+            if (act2) {
+              const int wxy = L.xy[w];
+              wx = wxy & 0xffff; wy = (wxy >> 16) & 0xffff;
+              const int dx = bu.g.x - wx, dy = bu.g.y - wy;
+              d2w = dx * dx + dy * dy;
+            }
+            if (need1) {                                     // alignment, reduced with min
+              double v1 = 0.0;
+              if (act2 && d2w <= maxd2_1) v1 = 1.0 - fabs(bu.g.ca * L.ca[w] + bu.g.sa * L.sa[w]) - rew;
+              unsigned long long bm = __ballot(v1 < 0.0);
+              while (bm) {
+                const int l2 = __ffsll((long long)bm) - 1;
+                bm &= bm - 1;
+                acc1 = reduce2(MPP_REDUCE_MIN, acc1, readlane_d(v1, l2));
+              }
+            }
+            if (need0) {                                     // overlap, reduced with max
+              bool needc = act2 && d2w <= maxd2_0;
+              Geo gw;
+              gw.x = wx; gw.y = wy; gw.hl = gw.hw = gw.ca = gw.sa = 0.0;
+              double mn = 0.0;
+              bool uf = false;
+              if (needc) {
+                gw.hl = L.hl[w]; gw.hw = L.hw[w]; gw.ca = L.ca[w]; gw.sa = L.sa[w];
+                const double B = geo_area(gw), reach = bu.rad + L.rad[w], d2 = (double)d2w;
+                mn = Aus < B ? Aus : B;
+                needc = !(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001);
+                if (needc) uf = slot_first(L, us, bu.g, wx, wy, L.s[w], L.r[w], L.a[w]);
+              }
+              unsigned long long m = __ballot(needc);
+              while (m) {
+                const int l2 = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                Geo bw;
+                bw.x = __builtin_amdgcn_readlane(gw.x, l2); bw.y = __builtin_amdgcn_readlane(gw.y, l2);
+                bw.hl = readlane_d(gw.hl, l2); bw.hw = readlane_d(gw.hw, l2);
+                bw.ca = readlane_d(gw.ca, l2); bw.sa = readlane_d(gw.sa, l2);
+                const bool u_first = __builtin_amdgcn_readlane((int)uf, l2) != 0;
+                const double mn2 = readlane_d(mn, l2);
+                double ux[4], uy[4], vx[4], vy[4];
+                geo_corners(bu.g, ux, uy); geo_corners(bw, vx, vy);
+                double sx[4], sy[4], cx[4], cy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  sx[q] = u_first ? ux[q] : vx[q]; sy[q] = u_first ? uy[q] : vy[q];
+                  cx[q] = u_first ? vx[q] : ux[q]; cy[q] = u_first ? vy[q] : uy[q];
+                }
+                acc0 = reduce2(MPP_REDUCE_MAX, acc0, clip_area_wave(c, sx, sy, cx, cy) / (mn2 + AREA_EPS));
+              }
+            }
+          }
+          if (ha_s) {                                        // the proposed rectangle is a neighbour too (uniform)
+            const int dx = bu.g.x - ba.g.x, dy = bu.g.y - ba.g.y, d2a2 = dx * dx + dy * dy;
+            if (need1 && d2a2 <= maxd2_1)
+              acc1 = reduce2(MPP_REDUCE_MIN, acc1, 1.0 - fabs(bu.g.ca * ba.g.ca + bu.g.sa * ba.g.sa) - rew);
+            if (need0 && d2a2 <= maxd2_0) {
+              const double B = geo_area(ba.g), mn = Aus < B ? Aus : B, reach = bu.rad + ba.rad, d2 = (double)d2a2;
+              if (!(mn < DEGENERATE_AREA) && !(d2 > reach * reach * 1.0000001)) {
+                const bool u_first = slot_first(L, us, bu.g, ba.g.x, ba.g.y, readlane_d(a_s, is), readlane_d(a_r, is), readlane_d(a_a, is));
+                double ux[4], uy[4], vx[4], vy[4];
+                geo_corners(bu.g, ux, uy); geo_corners(ba.g, vx, vy);
+                double sx[4], sy[4], cx[4], cy[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  sx[q] = u_first ? ux[q] : vx[q]; sy[q] = u_first ? uy[q] : vy[q];
+                  cx[q] = u_first ? vx[q] : ux[q]; cy[q] = u_first ? vy[q] : uy[q];
+                }
+                acc0 = reduce2(MPP_REDUCE_MAX, acc0, clip_area_wave(c, sx, sy, cx, cy) / (mn + AREA_EPS));
+              }
+            }
+          }
+          if (c.lane == src) {
+            if (need0) nv0 = acc0;
+            if (need1) nv1 = acc1;
+          }
+        }
+        // -- the neighbours whose energy changes, added to their step's sum in list order
+        const bool changed = act && (nv0 != ov0 || nv1 != ov1);
+        double de = 0.0;
+        if (changed) {
+          const double lin = L.lin[u];
+          const int gt = L.gate[u];
+          de = finish_energy_c(c, lin + pair_part_c(c, gt, nv0, nv1)) - finish_energy_c(c, lin + pair_part_c(c, gt, ov0, ov1));
+          if (apply) { L.red0[u] = nv0; L.red1[u] = nv1; }
+        }
+        unsigned long long cm = __ballot(changed);
+        while (cm) {
+          const int src = __ffsll((long long)cm) - 1;
+          cm &= cm - 1;
+          const int is = __builtin_amdgcn_readlane(i, src);
+          const double v = readlane_d(de, src);
+          if (c.lane == is) { sum += v; nchg += 1; }
+        }
+      }
+      M = 0;
+      wave_lds_fence();
+    }
+    if (final) break;
+  }
+  wave_lds_fence();
+  *sum_out = sum; *nchg_out = nchg;
+  *ra0_out = __longlong_as_double((long long)racc[c.lane]);
+  *ra1_out = __longlong_as_double((long long)racc[64 + c.lane]);
+  (void)below;
+}
+
+__device__ __forceinline__ unsigned long long low_mask(int k) { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull)); }
+
+template <int WAVES, bool DIAG, int OCC, bool FAST>
+__global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
+                                                                 const long long *until, long long trace_base,
+                                                                 unsigned long long seed, unsigned int chain0, int trace_tile,
+                                                                 mpp_step_out *out, mpp_proposal *props, int nmax,
+                                                                 int fixed_depth, unsigned long long *stats) {
+  constexpr int NCH = DEEP_NMAX_LIMIT / 64;              // chunks of 64 step reports a lane may have to look at
+  const DevParams *P = deep_stage_params<(WAVES >= MPP_LDS_PARAMS_MIN_WAVES)>(Pv, WAVE * WAVES);
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tile = tile0 + blockIdx.x;
+  Chain c;
+  c.P = P; c.t = tiles[tile];
+  load_model_regs(c);
+  load_hot(c);
+  const int ncell = P->nx * P->ny, cap = P->cap;
+  const int rowbase_n = P->rowbase_lds ? P->H + 1 : 0;
+  c.L = carve(lds_raw, cap, ncell, P->cell_cap, 0, rowbase_n, WAVES);
+  const DeepLds D = deep_carve(lds_raw + deep_base_bytes(cap, ncell, P->cell_cap, rowbase_n, WAVES), nmax, WAVES);
+  c.lane = threadIdx.x & (WAVE - 1);
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
+  const Lds &L = c.L;
+  const int tid = threadIdx.x, nthr = WAVE * WAVES;
+  const bool tracing = DIAG && (out != nullptr || props != nullptr) && tile == trace_tile;
+
+  // ---------------------------------------------------------------- load the configuration (as mpp_chain_kernel does)
+  int n0 = __builtin_amdgcn_readfirstlane(*c.t.n);
+  int err = __builtin_amdgcn_readfirstlane(*c.t.err);
+  if (n0 > cap) { n0 = cap; err = ERR_POINT_OVERFLOW; }
+  for (int i = tid; i < 3 * MPP_NCLASS; i += nthr) L.edges[i] = P->maps.edges[i / MPP_NCLASS][i % MPP_NCLASS];
+  for (int i = tid; i < MPP_NCLASS; i += nthr) {
+    const double al = P->maps.edges[2][i] + MPP_PI / 2.0;
+    L.trig[i] = cos(al); L.trig[MPP_NCLASS + i] = sin(al);
+  }
+  for (int i = tid; i < rowbase_n; i += nthr) L.rowbase[i] = c.t.rowbase[i];
+  for (int i = tid; i < cap; i += nthr) L.order[i] = (unsigned short)i;
+  for (int i = tid; i < ncell; i += nthr) L.cell_cnt[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < n0; i += nthr) {
+    Rect q{c.t.px[i], c.t.py[i], c.t.ps[i], c.t.pr[i], c.t.pa[i]};
+    Geo g = make_geo(q);
+    double lin; int gate;
+    unit_part<false>(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
+    L.xy[i] = (q.x & 0xffff) | (q.y << 16);
+    L.s[i] = q.s; L.r[i] = q.r; L.a[i] = q.a; L.ca[i] = g.ca; L.sa[i] = g.sa; L.hl[i] = g.hl; L.hw[i] = g.hw;
+    L.rad[i] = geo_radius(g);
+    L.lin[i] = lin; L.gate[i] = (unsigned char)gate; L.red0[i] = 0.0; L.red1[i] = 0.0;
+  }
+  __syncthreads();
+  const double alpha = c.t.T[1], T_target = c.t.T[2];
+  const int rmask = 2 * nmax - 1;
+  if (tid == 0) {                               // serial: keeps the cell order, hence the result, deterministic
+    for (int i = 0; i < n0; ++i) {
+      int xy = L.xy[i], ci, cj;
+      int cell = cell_index(c, xy & 0xffff, (xy >> 16) & 0xffff, &ci, &cj);
+      int cnt = L.cell_cnt[cell];
+      if (cnt >= P->cell_cap) { err = ERR_CELL_OVERFLOW; break; }
+      L.cell_items[(size_t)cell * P->cell_cap + cnt] = (unsigned short)i;
+      L.cell_cnt[cell] = (unsigned short)(cnt + 1);
+    }
+    L.sh[1] = err;
+  }
+  if (tid == nthr - 1) {                        // temperatures of the first nmax steps (rjmcmc.py:158-159, one multiply per step)
+    double Tc = *c.t.T;
+    for (int i = 0; i < nmax; ++i) { D.tring[i] = Tc; if (Tc > T_target) Tc *= alpha; }
+  }
+  __syncthreads();
+  err = __builtin_amdgcn_readfirstlane(L.sh[1]);
+  {                                             // cached pair reductions of the initial configuration
+    Rect dummy{0, 0, 0, 0, 0};
+    Geo2 dg;
+    dg.g = Geo{0, 0, 0, 0, 0, 0}; dg.rad = 0.0;
+    for (int u = tid; u < n0; u += nthr) {
+      Geo2 gu = load_geo(L, u);
+#pragma clang loop unroll(disable)
+      for (int p = 0; p < P->model.n_pair; ++p) {
+        double v = rescan_lane(c, p, u, gu, -1, false, dummy, dg);
+        if (p == 0) L.red0[u] = v; else L.red1[u] = v;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- the chain
+  const long long step0 = *c.t.step;
+  const long long n_steps = until[tile] - step0;
+  const long long tr0 = step0 - trace_base;
+  const unsigned long long seed_t = c.t.key_on ? (unsigned long long)c.t.key_seed : seed;
+  const uint32_t chain_t = c.t.key_on ? c.t.key_chain : chain0 + (uint32_t)tile;
+  const uint32_t k0 = (uint32_t)seed_t, k1 = (uint32_t)(seed_t >> 32);
+  const unsigned long long below = (1ull << c.lane) - 1ull;
+  long long done = 0;
+  int n = n0;                                   // the population, tracked by every wave
+  int depth = WAVES, ema16 = WAVES * 16;        // steps of the next round; committed steps per round, x16, smoothed
+  unsigned long long st_rounds = 0, st_eval = 0, st_apply = 0;
+#ifdef MPP_DEEP_PROF
+  unsigned long long dph_[12] = {0};
+#endif
+
+  // The loop alternates between two stages that share the call of eval_delta_lane: stage 1 draws and evaluates a round's
+  // steps and decides which commit; stage 0 (only after a round with a change) applies them.
+  int stage = 1;
+  Rec r;
+  r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r._pad = 0; r.tslot = -1; r.tidx = -1;
+  r.ax = r.ay = r.rx = r.ry = 0; r.as = r.ar = r.aa = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0; r.lin_a = 0.0; r.gate_a = 1;
+  bool mine = false, my_commit = false;
+  int myoff = 0, lim = 0, committed = 0, cur_n = n;
+  double Tm = 0.0;
+  while (stage == 0 || (done < n_steps && err == 0)) {
+    bool do_eval = my_commit;                   // stage 0: the steps that commit with a change
+    DPH_T0();
+    if (stage == 1) {
+    int N = fixed_depth > 0 ? fixed_depth : depth;
+    if (N > nmax) N = nmax;
+    const int Lw = N / WAVES;                   // active lanes per wave
+    const long long left = n_steps - done;
+    lim = left < (long long)N ? (int)left : N;
+    const bool act0 = c.lane < Lw;
+    const int e = c.wave * Lw + c.lane;         // my offset when the types are computed, my sorted position afterwards
+
+    // ---- A: kernel type of step done + e, counting sort by type over the workgroup
+    int kt = 15;
+    uint32_t w0[4] = {0u, 0u, 0u, 0u};
+    if (act0 && e < lim) {
+      const uint64_t s = (uint64_t)(step0 + done + e);
+      philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), 0u, chain_t, k0, k1, w0);
+      const double uk = u53(w0[0], w0[1]);
+      kt = 0;
+      while (kt < P->n_kernels - 1 && P->p_cum[kt] <= uk) ++kt;
+    }
+    unsigned long long same = 0ull;
+    int cnt_lane = 0;                           // lane k: steps of type k in this wave
+#pragma unroll
+    for (int k = 0; k < MPP_NKERNEL; ++k) {
+      const unsigned long long m = __ballot(kt == k);
+      if (kt == k) same = m;
+      if (c.lane == k) cnt_lane = __popcll(m);
+    }
+    const int rank = __popcll(same & below);
+    if (c.lane < 16) D.tcnt[c.wave * 16 + c.lane] = (unsigned short)cnt_lane;
+    DPH(0);
+    __syncthreads();                            // (1) also: the changes of the previous round are in place
+    DPH(1);
+    int tot = 0, pre = 0;
+    if (c.lane < 16) {
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const int v = D.tcnt[w * 16 + c.lane];
+        if (w < c.wave) pre += v;
+        tot += v;
+      }
+    }
+    int excl = 0, run = 0;
+#pragma unroll
+    for (int k = 0; k < MPP_NKERNEL; ++k) {
+      const int t_k = __builtin_amdgcn_readlane(tot, k);
+      if (c.lane == k) excl = run;
+      run += t_k;
+    }
+    const int first = __shfl(excl + pre, kt & 15, WAVE);
+    if (kt != 15) {
+      const int p = first + rank;
+      D.pw[p] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+      D.poff[p] = (unsigned short)e;
+    }
+    __syncthreads();                            // (2)
+    DPH(2);
+
+    // ---- B: evaluate my step
+    mine = act0 && e < lim;
+    myoff = mine ? (int)D.poff[e] : 0;
+    r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r.tslot = -1; r.tidx = -1;
+    if (mine) {
+      Tm = D.tring[(int)((done + myoff) & (long long)rmask)];
+      r.valid = 1;
+      int keep = 0;
+      MapVals pmv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
+      uint32_t w[8];
+      const uint4 wv = D.pw[e];
+      w[0] = wv.x; w[1] = wv.y; w[2] = wv.z; w[3] = wv.w;
+      const uint64_t s = (uint64_t)(step0 + done + myoff);
+      philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), 1u, chain_t, k0, k1, w + 4);
+      draw_proposal<true>(c, w, n, r, &keep, k0, k1, s, chain_t, &pmv);
+      DPH(3);
+      if (r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
+      if (r.valid && r.has_add && (r.ax < 0 || r.ax >= c.h.H || r.ay < 0 || r.ay >= c.h.W)) { r.valid = 0; r.kernel = -1; }
+      if (r.valid) deep_pre(c, r, keep, tracing, pmv);
+    }
+    do_eval = mine && r.valid && (r.has_rem || r.has_add);
+    DPH(4);
+    }
+    // ---- the neighbours' part of dE (energy_graph.py:139-225) for all steps of the wave; stage 0 writes their cached
+    //      reductions
+    {
+      double ra0 = 0.0, ra1 = 0.0, sde = 0.0;
+      int ns = 0;
+      const bool hr = r.has_rem != 0, ha = r.has_add != 0;
+      deep_delta(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
+                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns);
+      if (stage == 1 && do_eval) {
+        double dE = sde;
+        if (ha) dE += finish_energy_c(c, r.lin_a + pair_part_c(c, r.gate_a, ra0, ra1));
+        if (hr) dE -= finish_energy_c(c, L.lin[r.tslot] + pair_part_c(c, (int)L.gate[r.tslot], L.red0[r.tslot], L.red1[r.tslot]));
+        r.dE = dE; r.ra0 = ra0; r.ra1 = ra1; r.n_stash = ns;
+      }
+    }
+    DPH(stage == 1 ? 5 : 9);
+    if (stage == 1) {
+    if (mine) {
+      if (r.valid) deep_post(c, r, n, Tm, tracing);
+      // does the step change the configuration?  An accepted move that writes the values the slot already holds does not
+      // (its cached geometry, unit energy and reductions are functions of those values: the same bits)
+      bool chg = r.valid && r.accepted && (r.has_rem || r.has_add);
+      if (chg && r.has_rem && r.has_add) {
+        const int sl = r.tslot;
+        chg = !(r.ax == r.rx && r.ay == r.ry && r.as == L.s[sl] && r.ar == L.r[sl] && r.aa == L.a[sl]);
+      }
+      int f = (r.tslot & 0xffff) | (r.valid ? DI_VALID : DI_BAD) | (chg ? DI_CHG : 0) | (r.has_rem ? DI_HR : 0) |
+              (r.has_add ? DI_HA : 0) | (r.accepted ? DI_ACC : 0);
+      D.info[3 * myoff] = f;
+      D.info[3 * myoff + 1] = (r.rx & 0xffff) | (r.ry << 16);
+      D.info[3 * myoff + 2] = (r.ax & 0xffff) | (r.ay << 16);
+    }
+    DPH(6);
+    __syncthreads();                            // (3)
+    DPH(7);
+
+    // ---- C: which steps commit (every wave takes the same decision from the same reports)
+    int f_[NCH], pr_[NCH], pa_[NCH];
+    bool ok_[NCH];
+    unsigned long long am_[NCH], cm_[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int idx = ch * 64 + c.lane;
+      const bool in = idx < lim;
+      f_[ch] = in ? D.info[3 * idx] : 0; pr_[ch] = in ? D.info[3 * idx + 1] : 0; pa_[ch] = in ? D.info[3 * idx + 2] : 0;
+      ok_[ch] = in && (f_[ch] & DI_VALID);
+      am_[ch] = __ballot(in && (f_[ch] & DI_CHG));
+      cm_[ch] = 0ull;
+    }
+    int cur = 0;
+    committed = 0; cur_n = n;
+    bool any_commit = false;
+    while (true) {
+      int first_bad = lim;
+#pragma unroll
+      for (int ch = NCH - 1; ch >= 0; --ch) {
+        const unsigned long long bm = ~__ballot(ok_[ch]) & low_mask(lim - ch * 64);
+        if (bm) first_bad = ch * 64 + __ffsll((long long)bm) - 1;
+      }
+      int wq = -1;
+#pragma unroll
+      for (int ch = NCH - 1; ch >= 0; --ch) {
+        const unsigned long long t = am_[ch] & ~low_mask(cur - ch * 64) & low_mask(first_bad - ch * 64);
+        if (t) wq = ch * 64 + __ffsll((long long)t) - 1;
+      }
+      if (wq < 0) {
+        committed = first_bad;
+        if (first_bad < lim) {
+          int fb = 0;
+#pragma unroll
+          for (int ch = 0; ch < NCH; ++ch) if ((first_bad >> 6) == ch) fb = __builtin_amdgcn_readlane(f_[ch], first_bad & 63);
+          if (fb & DI_BAD) err = ERR_BAD_TARGET;
+          // otherwise: invalidated by an earlier commit of this round -> evaluated again next round
+        }
+        break;
+      }
+      int qf = 0, qr = 0, qa = 0;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch)
+        if ((wq >> 6) == ch) {
+          qf = __builtin_amdgcn_readlane(f_[ch], wq & 63); qr = __builtin_amdgcn_readlane(pr_[ch], wq & 63);
+          qa = __builtin_amdgcn_readlane(pa_[ch], wq & 63);
+        }
+      const bool q_hr = qf & DI_HR, q_ha = qf & DI_HA;
+      const int q_ts = qf & 0xffff, qrx = qr & 0xffff, qry = (qr >> 16) & 0xffff, qax = qa & 0xffff, qay = (qa >> 16) & 0xffff;
+      int ci, cj;
+      const int q_cr = q_hr ? cell_index(c, qrx, qry, &ci, &cj) : -1, q_ca = q_ha ? cell_index(c, qax, qay, &ci, &cj) : -2;
+      // capacity checks BEFORE anything of the step is applied: the chain stops in the state before it (see mpp_sampler.hip)
+      if (q_ha && q_ca != q_cr && (int)L.cell_cnt[q_ca] >= c.h.cell_cap) { err = ERR_CELL_OVERFLOW; committed = wq; break; }
+      if (!(q_hr && q_ha)) {                               // death / birth: ends the round (n and order[] change)
+        if (q_hr) cur_n -= 1;
+        else if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; committed = wq; break; }
+        else cur_n += 1;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
+        any_commit = true;
+        committed = wq + 1;
+        break;
+      }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
+      any_commit = true;
+      // is a later report still trustworthy after this move / transform?
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int idx = ch * 64 + c.lane;
+        if (idx > wq && ok_[ch]) {
+          const int mf = f_[ch];
+          const bool m_hr = mf & DI_HR, m_ha = mf & DI_HA;
+          const int mrx = pr_[ch] & 0xffff, mry = (pr_[ch] >> 16) & 0xffff, max_ = pa_[ch] & 0xffff, may = (pa_[ch] >> 16) & 0xffff;
+          const int m_cr = m_hr ? cell_index(c, mrx, mry, &ci, &cj) : -1, m_ca = m_ha ? cell_index(c, max_, may, &ci, &cj) : -2;
+          bool bad = (m_hr && (mf & 0xffff) == q_ts) || m_cr == q_cr || m_cr == q_ca || m_ca == q_cr || m_ca == q_ca;
+          const int ox[2] = {mrx, max_}, oy[2] = {mry, may};
+          const bool oh[2] = {m_hr, m_ha};
+          const int qx[2] = {qrx, qax}, qy[2] = {qry, qay};
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              if (oh[a]) {
+                const int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
+                if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
+              }
+          if (bad) ok_[ch] = false;
+        }
+      }
+      cur = wq + 1;
+    }
+
+    // ---- D: apply the committed changes
+    my_commit = false;
+    if (mine) {
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) if ((myoff >> 6) == ch) my_commit = (cm_[ch] >> (myoff & 63)) & 1ull;
+    }
+    if (DIAG && tracing && mine && myoff < committed) {
+      const long long idx = tr0 + done + myoff;
+      if (out) {
+        mpp_step_out so;
+        so.dE = r.dE; so.fwd = r.fwd; so.bwd = r.bwd; so.log_alpha = r.log_alpha; so.T = Tm;
+        so.accepted = r.accepted; so.n_after = (my_commit && !(r.has_rem && r.has_add)) ? cur_n : n;
+        out[idx] = so;
+      }
+      if (props) {
+        mpp_proposal pp;
+        pp.kernel = r.kernel; pp.target = r.has_rem ? r.tidx : -1; pp.ax = r.ax; pp.ay = r.ay; pp.as = r.as;
+        pp.ar = r.ar; pp.aa = r.aa; pp.aux0 = r.aux0; pp.aux1 = r.aux1; pp.param_id = r.pid;
+        pp.new_class = r.ncls; pp.u_accept = r.u_acc;
+        props[idx] = pp;
+      }
+    }
+    if (tid == nthr - 1) {                      // temperatures of the steps that enter the window
+      double Tc = D.tring[(int)((done + nmax - 1) & (long long)rmask)];
+      for (int i = 0; i < committed; ++i) {
+        if (Tc > T_target) Tc *= alpha;
+        D.tring[(int)((done + nmax + i) & (long long)rmask)] = Tc;
+      }
+    }
+    DPH(8);
+    if (stats) { st_rounds += 1; st_eval += (unsigned long long)lim; if (any_commit) st_apply += 1; }
+    // depth of the next round: about twice what the last rounds committed
+    ema16 += committed - (ema16 >> 4);
+    {
+      int want = (ema16 >> 3) + WAVES;          // 2 * mean + WAVES
+      want = (want + WAVES - 1) / WAVES * WAVES;
+      depth = want < WAVES ? WAVES : (want > nmax ? nmax : want);
+    }
+    if (any_commit) stage = 0;
+    else { done += committed; }                 // (n is unchanged)
+    } else {
+      // ---- D: the committed changes (stage 0; their neighbours' reductions were written just above)
+      __syncthreads();                          // (4) every reduction is written before a list or a slot changes
+      DPH(10);
+      if (my_commit) {
+        int ci, cj;
+        if (r.has_rem && r.has_add) {
+          const int c0 = cell_index(c, r.rx, r.ry, &ci, &cj), c1 = cell_index(c, r.ax, r.ay, &ci, &cj);
+          if (c0 != c1) { cell_remove_1(c, c0, r.tslot); cell_insert_1(c, c1, r.tslot); }
+          write_slot_1(c, r.tslot, r);
+        } else if (r.has_rem) {
+          cell_remove_1(c, cell_index(c, r.rx, r.ry, &ci, &cj), r.tslot);
+          const unsigned short last = L.order[n - 1];
+          L.order[n - 1] = (unsigned short)r.tslot;
+          L.order[r.tidx] = last;
+        } else {
+          const int slot = L.order[n];
+          cell_insert_1(c, cell_index(c, r.ax, r.ay, &ci, &cj), slot);
+          write_slot_1(c, slot, r);
+        }
+      }
+      my_commit = false;
+      done += committed;
+      n = cur_n;
+      stage = 1;
+      DPH(11);
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- write the configuration back
+  for (int i = tid; i < n; i += nthr) {
+    int slot = L.order[i], xy = L.xy[slot];
+    c.t.px[i] = xy & 0xffff; c.t.py[i] = (xy >> 16) & 0xffff;
+    c.t.ps[i] = L.s[slot]; c.t.pr[i] = L.r[slot]; c.t.pa[i] = L.a[slot];
+  }
+  if (tid == 0) {
+    *c.t.n = n; *c.t.err = err; *c.t.step = step0 + done;
+    *c.t.T = D.tring[(int)(done & (long long)rmask)];
+#ifdef MPP_DEEP_PROF
+    if (stats) for (int i = 0; i < 12; ++i) atomicAdd(stats + 4 + i, dph_[i]);
+#endif
+    if (stats) { atomicAdd(stats, st_rounds); atomicAdd(stats + 1, st_eval); atomicAdd(stats + 2, st_apply); atomicAdd(stats + 3, (unsigned long long)done); }
+  }
+}
+
+// ---- host-side launcher ----------------------------------------------------------------------------
+extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax) {
+  return deep_base_bytes(cap, ncell, cell_cap, rowbase_n, waves) + deep_extra_bytes(nmax, waves);
+}
+extern "C" size_t mpp_deep_static_lds_bytes(int waves) {
+  return waves >= MPP_LDS_PARAMS_MIN_WAVES ? ((sizeof(DevParams) + 15) & ~(size_t)15) : 0;
+}
+
+template <int WAVES, bool DIAG, int OCC>
+static hipError_t launch_deep_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
+                                const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
+                                int trace_tile, mpp_step_out *out, mpp_proposal *props, int nmax, int fixed_depth,
+                                unsigned long long *stats) {
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_deep_kernel<WAVES, DIAG, OCC, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((mpp_deep_kernel<WAVES, DIAG, OCC, true>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0, until,
+                     trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats);
+  return hipGetLastError();
+}
+
+// waves = waves per chain (1, 2, 4, 8); nmax = most steps of one round (a power of two, waves <= nmax <= 64 * waves, <= 512)
+extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
+                                      const TileRef *tiles, int tile0, const long long *until, long long trace_base,
+                                      unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
+                                      mpp_proposal *props, int nmax, int fixed_depth, unsigned long long *stats) {
+  const bool diag = out || props;
+#define GO(W, O)                                                                                                          \
+  return diag ? launch_deep_d<W, true, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats) \
+              : launch_deep_d<W, false, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats)
+  switch (waves) {
+    case 1: if (occ >= 2) { GO(1, 2); } GO(1, 1);
+    case 2: if (occ >= 2) { GO(2, 2); } GO(2, 1);
+    case 4: if (occ >= 2) { GO(4, 2); } GO(4, 1);
+    case 8: GO(8, 2);
+  }
+#undef GO
+  return hipErrorInvalidValue;
+}

@@ -193,7 +193,8 @@ class MppContext:
     """One GPU context holding ``n_tiles`` tiles of equal shape (thin, 1:1 over the C ABI)."""
 
     def __init__(self, device: int = 0, point_capacity: Optional[int] = None, cell_capacity: Optional[int] = None,
-                 spec_waves: Optional[int] = None, spec_lanes: Optional[int] = None, replicas: Optional[int] = None):
+                 spec_waves: Optional[int] = None, spec_lanes: Optional[int] = None, replicas: Optional[int] = None,
+                 deep: Optional[int] = None):
         self._L = load_library()
         h = C.c_void_p()
         rc = self._L.mpp_create(int(device), C.byref(h))
@@ -216,6 +217,8 @@ class MppContext:
             self.set_option("spec_lanes", spec_lanes)
         if replicas is not None:
             self.set_option("replicas", replicas)
+        if deep is not None:
+            self.set_option("deep", deep)
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -440,6 +443,11 @@ class MppContext:
         if len(seeds) != len(chains):
             raise ValueError("one seed and one chain id per chain")
         self._check(self._L.mpp_set_chain_keys(self._h, len(seeds), _ptr(seeds), _ptr(chains)))
+
+    def deep_stats(self) -> dict:
+        """counters of the last run's deep rounds (all tiles): rounds, steps evaluated, rounds with a change, steps committed"""
+        v = [self.get_option(f"deep_stat{i}") for i in range(4)]
+        return {"rounds": v[0], "evaluated": v[1], "rounds_with_change": v[2], "committed": v[3]}
 
     def step_index(self, tile: int = 0) -> int:
         s = C.c_int64()
