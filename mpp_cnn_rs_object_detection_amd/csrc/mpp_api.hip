@@ -246,10 +246,10 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     if (v != 0 && v != 1 && v != 2 && v != 4 && v != 8 && v != 16) return fail(c, -1, "spec_lanes must be 0, 1, 2, 4, 8 or 16");
     c->lanes = (int)v;
   } else if (!strcmp(name, "deep")) {
-    if (v != 0 && (v < 8 || v > 512 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..512");
+    if (v != 0 && (v < 8 || v > 256 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..256");
     c->deep = (int)v;
   } else if (!strcmp(name, "deep_fixed")) {
-    if (v < 0 || v > 512) return fail(c, -1, "deep_fixed must be in 0..512");
+    if (v < 0 || v > 256) return fail(c, -1, "deep_fixed must be in 0..256");
     c->deep_fixed = (int)v;
   } else if (!strcmp(name, "replicas")) {
     // independent replica chains per tile: mpp_set_maps(n_tiles = M) then creates M*v chains, chain t on the maps
@@ -284,10 +284,10 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "spec_lanes")) return c->lanes;
   if (!strcmp(name, "deep")) return c->deep;
   if (!strcmp(name, "deep_fixed")) return c->deep_fixed;
-  if (!strncmp(name, "deep_stat", 9) && name[9] >= '0' && name[9] <= '9') {      // deep_stat0 .. deep_stat15
+  if (!strncmp(name, "deep_stat", 9) && name[9] >= '0' && name[9] <= '9') {      // deep_stat0 .. deep_stat255 (4 counters, then the per-wave phase clocks of the diagnostic build)
     const int i = atoi(name + 9);
-    unsigned long long v[16] = {0};
-    if (i > 15) return -1;
+    unsigned long long v[256] = {0};
+    if (i > 255) return -1;
     if (c->deep_stats && hipMemcpy(v, c->deep_stats, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)v[i];
   }
@@ -930,9 +930,9 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
       if (deep_nmax < c->spec) deep_nmax = c->spec;
       if (c->H <= 1024) c->hp.rowbase_lds = 1;
       if (!c->deep_stats) {
-        HIPCHK(c, hipMalloc((void **)&c->deep_stats, 16 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc((void **)&c->deep_stats, 256 * sizeof(unsigned long long)));
       }
-      HIPCHK(c, hipMemsetAsync(c->deep_stats, 0, 16 * sizeof(unsigned long long), c->stream));
+      HIPCHK(c, hipMemsetAsync(c->deep_stats, 0, 256 * sizeof(unsigned long long), c->stream));
     }
   }
   mpp_launch_set_until(c->stream, c->d_tiles, tile0, grid, (long long)n_steps, c->until);

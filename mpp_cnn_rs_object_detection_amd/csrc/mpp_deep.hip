@@ -24,16 +24,21 @@
 
 #include "mpp_chain.hpp"
 
-#define DEEP_NMAX_LIMIT 512
+#define DEEP_NMAX_LIMIT 256      // most steps of one round (deeper rounds commit no more: the first conflict ends them)
 #define DEEP_CLIST 192         // candidate neighbours a wave collects before it evaluates them (>= 64: one cell's entries fit)
 #ifdef MPP_DEEP_PROF
 // diagnostic build only (profiles/tools/build_deep_prof.sh): cycles of wave 0 per phase of a round, summed over the launch,
-// in stats[4..15]
-#define DPH_T0() unsigned long long dph_t_ = clock64()
+// in stats[16 + 24 * wave + phase]
+#define DPH_N 24
+#define DPH_T0() dph_t_ = clock64()
 #define DPH(i) do { const unsigned long long n_ = clock64(); dph_[i] += n_ - dph_t_; dph_t_ = n_; } while (0)
+#define DPH_ARGS , unsigned long long *dph_, unsigned long long &dph_t_
+#define DPH_PASS , dph_, dph_t_
 #else
 #define DPH_T0()
 #define DPH(i)
+#define DPH_ARGS
+#define DPH_PASS
 #endif
 // info word 0: bits 0..15 slot, then flags
 #define DI_VALID (1 << 16)
@@ -42,6 +47,8 @@
 #define DI_HA (1 << 19)
 #define DI_BAD (1 << 20)     // the proposal could not be formed (reported when the commit reaches it)
 #define DI_ACC (1 << 21)
+#define DI_FULL (1 << 22)    // the cell the step adds to is full (capacity check, made against the round's start state)
+#define DI_NB (1 << 23)      // the step changes cached reductions of neighbours: committing it needs the second pass
 
 struct DeepLds {
   int *info;                   // [nmax][3]: flags | slot, removed xy, added xy -- indexed by the step's offset in the round
@@ -51,10 +58,11 @@ struct DeepLds {
   double *tring;               // [2 * nmax] temperature of step (offset & mask)
   unsigned long long *racc;    // [WAVES][2][64] per step of a wave: max of the overlaps / min of the alignments with the added point
   unsigned int *clist;         // [WAVES][DEEP_CLIST] (step << 16 | slot): the neighbours in range of a wave's steps, in order
+  unsigned char *ltab;         // [WAVES][64] the lanes that lead a step, in lane order
 };
 __host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
   return (size_t)nmax * 16 + (size_t)2 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 12 +
-         (size_t)nmax * 2 + (size_t)waves * 16 * 2 + 64;
+         (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 64 + 64;
 }
 __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
   return (lds_bytes(cap, ncell, cell_cap, 0, rowbase_n, waves) + 15) & ~(size_t)15;
@@ -67,7 +75,8 @@ __device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
   D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
   D.info = (int *)base; base += (size_t)nmax * 12;
   D.poff = (unsigned short *)base; base += (size_t)nmax * 2;
-  D.tcnt = (unsigned short *)base;
+  D.tcnt = (unsigned short *)base; base += (size_t)waves * 16 * 2;
+  D.ltab = base;
   return D;
 }
 
@@ -167,6 +176,63 @@ __device__ __forceinline__ double shfl_d(double v, int lane) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// clip_area_wave() for up to CLIP_SLOTS rectangle pairs at once: the wave works in groups of 16 lanes, lane li < 8 of a group
+// owns vertex li of its group's polygon (the group's two polygon buffers are those of one clip slot).  Every vertex goes
+// through exactly the arithmetic of clip_area() / clip_area_wave(), the shoelace sum runs in vertex order: the same bits.
+// A data-driven birth lands on an object, i.e. on the rectangle that already sits there: nearly every birth asks for a
+// clip, ten per wave and round -- one after the other they were a third of the neighbour evaluation.
+// `gact`: my group has a pair; sx .. cy: its subject and clip corners (the same in all lanes of the group).
+__device__ __forceinline__ double clip_area_groups(const Chain &c, bool gact, const double *sx, const double *sy, const double *cx,
+                                                   const double *cy) {
+  const int g = c.lane >> 4, li = c.lane & 15;
+  double *buf = c.L.clip + ((size_t)c.wave * CLIP_SLOTS + g) * 32;
+  double *ax = buf, *ay = buf + 8, *bx = buf + 16, *by = buf + 24;
+  if (li < 4) {
+    ax[li] = li == 0 ? sx[0] : (li == 1 ? sx[1] : (li == 2 ? sx[2] : sx[3]));
+    ay[li] = li == 0 ? sy[0] : (li == 1 ? sy[1] : (li == 2 ? sy[2] : sy[3]));
+  }
+  wave_lds_fence();
+  const unsigned int belowg = (1u << li) - 1u;
+  int na = gact ? 4 : 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const double x0 = cx[e], y0 = cy[e], x1 = cx[(e + 1) & 3], y1 = cy[(e + 1) & 3];
+    const double ex = x1 - x0, ey = y1 - y0;
+    const bool valid = li < na;
+    const int ii = valid ? li : 0, pi = ii == 0 ? (na > 0 ? na - 1 : 0) : ii - 1;
+    const double qx = ax[ii], qy = ay[ii], px = ax[pi], py = ay[pi];
+    const double sq = ex * (qy - y0) - ey * (qx - x0), sp = ex * (py - y0) - ey * (px - x0);
+    const bool e_int = valid && (sq >= 0 ? sp < 0 : sp >= 0), e_q = valid && sq >= 0;
+    const unsigned int mi = (unsigned int)(__ballot(e_int) >> (16 * g)) & 0xffffu, mq = (unsigned int)(__ballot(e_q) >> (16 * g)) & 0xffffu;
+    int off = __popc(mi & belowg) + __popc(mq & belowg);
+    if (e_int) {
+      if (off < 8) {
+        double t = sp / (sp - sq);
+        bx[off] = px + t * (qx - px); by[off] = py + t * (qy - py);
+      }
+      ++off;
+    }
+    if (e_q && off < 8) { bx[off] = qx; by[off] = qy; }
+    const int nb = __popc(mi) + __popc(mq);
+    na = nb < 8 ? nb : 8;
+    double *tx = ax, *ty = ay;
+    ax = bx; ay = by; bx = tx; by = ty;
+    wave_lds_fence();
+  }
+  const bool valid = li < na;
+  const int ii = valid ? li : 0, jj = ii + 1 >= na ? 0 : ii + 1;
+  if (li < 8) bx[li] = valid ? ax[ii] * ay[jj] - ax[jj] * ay[ii] : 0.0;
+  wave_lds_fence();
+  double t_[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) t_[i] = bx[i];
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) if (i < na) s += t_[i];
+  wave_lds_fence();
+  return na < 3 ? 0.0 : 0.5 * fabs(s);
+}
+
 // The neighbours' part of dE for ALL steps a wave evaluates (energy_graph.py:139-225; the arithmetic of eval_delta<FAST>,
 // mpp_chain.hpp, per neighbour, summed in the same order).  Lane i leads step i (`lead`: it has a point to remove and / or a
 // rectangle to add).  One lane walking the 3 x 3 cells around its own step's points is a chain of dependent LDS reads per
@@ -184,7 +250,7 @@ __device__ __forceinline__ double shfl_d(double v, int lane) {
 __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, bool lead, bool has_rem, bool has_add, int rem,
                                            int rxy, int axy, double a_s, double a_r, double a_a, double a_hl, double a_hw,
                                            double a_ca, double a_sa, double a_rad, bool apply, double *sum_out, double *ra0_out,
-                                           double *ra1_out, int *nchg_out) {
+                                           double *ra1_out, int *nchg_out DPH_ARGS) {
   const Lds &L = c.L;
   unsigned int *clist = D.clist + (size_t)c.wave * DEEP_CLIST;
   unsigned long long *racc = D.racc + (size_t)c.wave * 128;
@@ -193,8 +259,9 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   const double rew = c.pr1.p0 != 0.0 ? 1.0 : 0.0;
   const unsigned long long below = (1ull << c.lane) - 1ull;
   const unsigned long long leadm = __ballot(lead);
-  const int nlead = leadm ? 64 - __clzll((long long)leadm) : 0;
-  const int ntasks = 18 * nlead;
+  const int ntasks = 18 * __popcll(leadm);
+  unsigned char *ltab = D.ltab + (size_t)c.wave * 64;
+  if (lead) ltab[__popcll(leadm & below)] = (unsigned char)c.lane;
   racc[c.lane] = 0ull; racc[64 + c.lane] = 0ull;
   wave_lds_fence();
   double sum = 0.0;
@@ -210,9 +277,9 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
         // ---- 1: the next 64 (step, cell) pairs
         const int t = t0 + c.lane;
         t0 += WAVE;
-        const int i = (t * 3641) >> 16, k = t - 18 * i;            // t / 18, t % 18 (t < 1152)
-        const int sfl = __shfl(flags, i & 63, WAVE), srem = __shfl(rem, i & 63, WAVE), srxy = __shfl(rxy, i & 63, WAVE),
-                  saxy = __shfl(axy, i & 63, WAVE);
+        const int ir = (t * 3641) >> 16, k = t - 18 * ir;          // t / 18, t % 18 (t < 1152)
+        const int i = t < ntasks ? (int)ltab[ir] : 0;               // the lane that leads the task's step
+        const int sfl = __shfl(flags, i, WAVE), srem = __shfl(rem, i, WAVE), srxy = __shfl(rxy, i, WAVE), saxy = __shfl(axy, i, WAVE);
         const bool s_hr = sfl & 1, s_ha = sfl & 2;
         const int rx = srxy & 0xffff, ry = (srxy >> 16) & 0xffff, ax = saxy & 0xffff, ay = (saxy >> 16) & 0xffff;
         const int cir = cell_coord(c, rx), cjr = cell_coord(c, ry), cia = cell_coord(c, ax), cja = cell_coord(c, ay);
@@ -242,6 +309,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
         }
         p_cnt = __popcll(mask); p_mask = mask; p_base = base; p_i = i;
         pending = p_cnt > 0;
+        DPH(12);
       }
     }
     bool flush = final;
@@ -263,6 +331,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
       }
       if (fm) M = __builtin_amdgcn_readlane(M + incl, 63 - __clzll((long long)fm));
       flush = __ballot(pending) != 0ull;                   // what is left did not fit: evaluate the list first
+      DPH(13);
     }
     if (flush && M > 0) {
       wave_lds_fence();
@@ -291,6 +360,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
         const bool tie_a = s_ha && gu.g.x == ag.g.x && gu.g.y == ag.g.y;
         double sa_s = 0.0, sa_r = 0.0, sa_a = 0.0;
         if (__ballot(tie_a) != 0ull) { sa_s = shfl_d(a_s, i); sa_r = shfl_d(a_r, i); sa_a = shfl_d(a_a, i); }
+        DPH(14);
         // -- overlaps first, in uniform control flow: every pair whose circumscribed circles meet is clipped by the wave
         const bool in_r0 = s_hr && d2r <= maxd2_0 && ov0 != 0.0, in_a0 = s_ha && d2a <= maxd2_0;
         const double Au = geo_area(gu.g);
@@ -312,17 +382,23 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
           }
           double val = 0.0;
           unsigned long long m = __ballot(need);
-          while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
+          while (m) {                                              // CLIP_SLOTS pairs at a time, one per group of 16 lanes
+            const int rank = __popcll(m & below);                  // my place among the lanes that still wait
+            int my_src = -1;
+#pragma unroll
+            for (int k = 0; k < CLIP_SLOTS; ++k) {
+              const int sk = m ? __ffsll((long long)m) - 1 : -1;
+              if (m) m &= m - 1;
+              if ((c.lane >> 4) == k) my_src = sk;
+            }
+            const bool gact = my_src >= 0;
+            const int sl = gact ? my_src : 0;
             Geo bu, bv;
-            bu.x = __builtin_amdgcn_readlane(gu.g.x, src); bu.y = __builtin_amdgcn_readlane(gu.g.y, src);
-            bu.hl = readlane_d(gu.g.hl, src); bu.hw = readlane_d(gu.g.hw, src);
-            bu.ca = readlane_d(gu.g.ca, src); bu.sa = readlane_d(gu.g.sa, src);
-            bv.x = __builtin_amdgcn_readlane(gv.g.x, src); bv.y = __builtin_amdgcn_readlane(gv.g.y, src);
-            bv.hl = readlane_d(gv.g.hl, src); bv.hw = readlane_d(gv.g.hw, src);
-            bv.ca = readlane_d(gv.g.ca, src); bv.sa = readlane_d(gv.g.sa, src);
-            const bool u_first = __builtin_amdgcn_readlane((int)uf, src) != 0;
+            bu.x = __shfl(gu.g.x, sl, WAVE); bu.y = __shfl(gu.g.y, sl, WAVE);
+            bu.hl = shfl_d(gu.g.hl, sl); bu.hw = shfl_d(gu.g.hw, sl); bu.ca = shfl_d(gu.g.ca, sl); bu.sa = shfl_d(gu.g.sa, sl);
+            bv.x = __shfl(gv.g.x, sl, WAVE); bv.y = __shfl(gv.g.y, sl, WAVE);
+            bv.hl = shfl_d(gv.g.hl, sl); bv.hw = shfl_d(gv.g.hw, sl); bv.ca = shfl_d(gv.g.ca, sl); bv.sa = shfl_d(gv.g.sa, sl);
+            const bool u_first = __shfl((int)uf, sl, WAVE) != 0;
             double ux[4], uy[4], vx[4], vy[4];
             geo_corners(bu, ux, uy); geo_corners(bv, vx, vy);
             double sx[4], sy[4], cx[4], cy[4];          // subject = the smaller rectangle in the canonical order
@@ -331,11 +407,13 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
               sx[q] = u_first ? ux[q] : vx[q]; sy[q] = u_first ? uy[q] : vy[q];
               cx[q] = u_first ? vx[q] : ux[q]; cy[q] = u_first ? vy[q] : uy[q];
             }
-            const double area = clip_area_wave(c, sx, sy, cx, cy);
-            if (c.lane == src) val = area / (mn + AREA_EPS);
+            const double area = clip_area_groups(c, gact, sx, sy, cx, cy);
+            const double mine_ = shfl_d(area, (rank & (CLIP_SLOTS - 1)) << 4);
+            if (need && rank < CLIP_SLOTS) { val = mine_ / (mn + AREA_EPS); need = false; }
           }
           if (which == 0) ovl_r = val; else ovl_a = val;
         }
+        DPH(15);
         // -- the two reductions of the neighbour (MPP_PAIR_P of eval_delta)
         double nv0 = ov0, nv1 = ov1;
         bool resc0 = false, resc1 = false;
@@ -490,6 +568,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
             if (need1) nv1 = acc1;
           }
         }
+        DPH(16);
         // -- the neighbours whose energy changes, added to their step's sum in list order
         const bool changed = act && (nv0 != ov0 || nv1 != ov1);
         double de = 0.0;
@@ -507,6 +586,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
           const double v = readlane_d(de, src);
           if (c.lane == is) { sum += v; nchg += 1; }
         }
+        DPH(17);
       }
       M = 0;
       wave_lds_fence();
@@ -517,9 +597,27 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   *sum_out = sum; *nchg_out = nchg;
   *ra0_out = __longlong_as_double((long long)racc[c.lane]);
   *ra1_out = __longlong_as_double((long long)racc[64 + c.lane]);
-  (void)below;
 }
 
+// the state change of a committed step, done by the lane that evaluated it (n: the population at the round's start)
+__device__ __forceinline__ void deep_mutate(const Chain &c, const Rec &r, int n) {
+  const Lds &L = c.L;
+  int ci, cj;
+  if (r.has_rem && r.has_add) {                        // move / transform: same slot
+    const int c0 = cell_index(c, r.rx, r.ry, &ci, &cj), c1 = cell_index(c, r.ax, r.ay, &ci, &cj);
+    if (c0 != c1) { cell_remove_1(c, c0, r.tslot); cell_insert_1(c, c1, r.tslot); }
+    write_slot_1(c, r.tslot, r);
+  } else if (r.has_rem) {                              // death: last index takes the hole
+    cell_remove_1(c, cell_index(c, r.rx, r.ry, &ci, &cj), r.tslot);
+    const unsigned short last = L.order[n - 1];
+    L.order[n - 1] = (unsigned short)r.tslot;
+    L.order[r.tidx] = last;
+  } else {                                             // birth: next free slot
+    const int slot = L.order[n];
+    cell_insert_1(c, cell_index(c, r.ax, r.ay, &ci, &cj), slot);
+    write_slot_1(c, slot, r);
+  }
+}
 __device__ __forceinline__ unsigned long long low_mask(int k) { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull)); }
 
 template <int WAVES, bool DIAG, int OCC, bool FAST>
@@ -617,7 +715,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   int depth = WAVES, ema16 = WAVES * 16;        // steps of the next round; committed steps per round, x16, smoothed
   unsigned long long st_rounds = 0, st_eval = 0, st_apply = 0;
 #ifdef MPP_DEEP_PROF
-  unsigned long long dph_[12] = {0};
+  unsigned long long dph_[DPH_N] = {0}, dph_t_ = 0;
 #endif
 
   // The loop alternates between two stages that share the call of eval_delta_lane: stage 1 draws and evaluates a round's
@@ -630,7 +728,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   int myoff = 0, lim = 0, committed = 0, cur_n = n;
   double Tm = 0.0;
   while (stage == 0 || (done < n_steps && err == 0)) {
-    bool do_eval = my_commit;                   // stage 0: the steps that commit with a change
+    bool do_eval = my_commit && r.n_stash > 0;  // stage 0: the steps that commit and change reductions of neighbours
     DPH_T0();
     if (stage == 1) {
     int N = fixed_depth > 0 ? fixed_depth : depth;
@@ -719,7 +817,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       int ns = 0;
       const bool hr = r.has_rem != 0, ha = r.has_add != 0;
       deep_delta(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
-                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns);
+                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns DPH_PASS);
       if (stage == 1 && do_eval) {
         double dE = sde;
         if (ha) dE += finish_energy_c(c, r.lin_a + pair_part_c(c, r.gate_a, ra0, ra1));
@@ -738,8 +836,14 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
         const int sl = r.tslot;
         chg = !(r.ax == r.rx && r.ay == r.ry && r.as == L.s[sl] && r.ar == L.r[sl] && r.aa == L.a[sl]);
       }
+      bool full = false;
+      if (chg && r.has_add) {
+        int ci, cj;
+        const int c1 = cell_index(c, r.ax, r.ay, &ci, &cj), c0 = r.has_rem ? cell_index(c, r.rx, r.ry, &ci, &cj) : -1;
+        full = c1 != c0 && (int)L.cell_cnt[c1] >= c.h.cell_cap;
+      }
       int f = (r.tslot & 0xffff) | (r.valid ? DI_VALID : DI_BAD) | (chg ? DI_CHG : 0) | (r.has_rem ? DI_HR : 0) |
-              (r.has_add ? DI_HA : 0) | (r.accepted ? DI_ACC : 0);
+              (r.has_add ? DI_HA : 0) | (r.accepted ? DI_ACC : 0) | (full ? DI_FULL : 0) | (chg && r.n_stash > 0 ? DI_NB : 0);
       D.info[3 * myoff] = f;
       D.info[3 * myoff + 1] = (r.rx & 0xffff) | (r.ry << 16);
       D.info[3 * myoff + 2] = (r.ax & 0xffff) | (r.ay << 16);
@@ -752,31 +856,36 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     int f_[NCH], pr_[NCH], pa_[NCH];
     bool ok_[NCH];
     unsigned long long am_[NCH], cm_[NCH];
+    const int nch = (lim + 63) >> 6;            // chunks in use
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      const int idx = ch * 64 + c.lane;
-      const bool in = idx < lim;
-      f_[ch] = in ? D.info[3 * idx] : 0; pr_[ch] = in ? D.info[3 * idx + 1] : 0; pa_[ch] = in ? D.info[3 * idx + 2] : 0;
-      ok_[ch] = in && (f_[ch] & DI_VALID);
-      am_[ch] = __ballot(in && (f_[ch] & DI_CHG));
-      cm_[ch] = 0ull;
+      f_[ch] = 0; pr_[ch] = 0; pa_[ch] = 0; ok_[ch] = false; am_[ch] = 0ull; cm_[ch] = 0ull;
+      if (ch < nch) {
+        const int idx = ch * 64 + c.lane;
+        const bool in = idx < lim;
+        f_[ch] = in ? D.info[3 * idx] : 0; pr_[ch] = in ? D.info[3 * idx + 1] : 0; pa_[ch] = in ? D.info[3 * idx + 2] : 0;
+        ok_[ch] = in && (f_[ch] & DI_VALID);
+        am_[ch] = __ballot(in && (f_[ch] & DI_CHG));
+      }
     }
     int cur = 0;
     committed = 0; cur_n = n;
-    bool any_commit = false;
+    bool any_commit = false, any_apply = false;     // a step commits with a change; ... and changes reductions of neighbours
     while (true) {
       int first_bad = lim;
 #pragma unroll
-      for (int ch = NCH - 1; ch >= 0; --ch) {
-        const unsigned long long bm = ~__ballot(ok_[ch]) & low_mask(lim - ch * 64);
-        if (bm) first_bad = ch * 64 + __ffsll((long long)bm) - 1;
-      }
+      for (int ch = NCH - 1; ch >= 0; --ch)
+        if (ch < nch) {
+          const unsigned long long bm = ~__ballot(ok_[ch]) & low_mask(lim - ch * 64);
+          if (bm) first_bad = ch * 64 + __ffsll((long long)bm) - 1;
+        }
       int wq = -1;
 #pragma unroll
-      for (int ch = NCH - 1; ch >= 0; --ch) {
-        const unsigned long long t = am_[ch] & ~low_mask(cur - ch * 64) & low_mask(first_bad - ch * 64);
-        if (t) wq = ch * 64 + __ffsll((long long)t) - 1;
-      }
+      for (int ch = NCH - 1; ch >= 0; --ch)
+        if (ch < nch) {
+          const unsigned long long t = am_[ch] & ~low_mask(cur - ch * 64) & low_mask(first_bad - ch * 64);
+          if (t) wq = ch * 64 + __ffsll((long long)t) - 1;
+        }
       if (wq < 0) {
         committed = first_bad;
         if (first_bad < lim) {
@@ -800,7 +909,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       int ci, cj;
       const int q_cr = q_hr ? cell_index(c, qrx, qry, &ci, &cj) : -1, q_ca = q_ha ? cell_index(c, qax, qay, &ci, &cj) : -2;
       // capacity checks BEFORE anything of the step is applied: the chain stops in the state before it (see mpp_sampler.hip)
-      if (q_ha && q_ca != q_cr && (int)L.cell_cnt[q_ca] >= c.h.cell_cap) { err = ERR_CELL_OVERFLOW; committed = wq; break; }
+      // (the evaluating lane looked at the cell's count: no state is read here, see "stage")
+      if (qf & DI_FULL) { err = ERR_CELL_OVERFLOW; committed = wq; break; }
       if (!(q_hr && q_ha)) {                               // death / birth: ends the round (n and order[] change)
         if (q_hr) cur_n -= 1;
         else if (cur_n >= cap) { err = ERR_POINT_OVERFLOW; committed = wq; break; }
@@ -808,17 +918,19 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
         any_commit = true;
+        if (qf & DI_NB) any_apply = true;
         committed = wq + 1;
         break;
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
       any_commit = true;
+      if (qf & DI_NB) any_apply = true;
       // is a later report still trustworthy after this move / transform?
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const int idx = ch * 64 + c.lane;
-        if (idx > wq && ok_[ch]) {
+        if (ch < nch && ch * 64 + 63 > wq && idx > wq && ok_[ch]) {
           const int mf = f_[ch];
           const bool m_hr = mf & DI_HR, m_ha = mf & DI_HA;
           const int mrx = pr_[ch] & 0xffff, mry = (pr_[ch] >> 16) & 0xffff, max_ = pa_[ch] & 0xffff, may = (pa_[ch] >> 16) & 0xffff;
@@ -871,7 +983,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       }
     }
     DPH(8);
-    if (stats) { st_rounds += 1; st_eval += (unsigned long long)lim; if (any_commit) st_apply += 1; }
+    if (stats) { st_rounds += 1; st_eval += (unsigned long long)lim; if (any_apply) st_apply += 1; }
     // depth of the next round: about twice what the last rounds committed
     ema16 += committed - (ema16 >> 4);
     {
@@ -879,29 +991,21 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       want = (want + WAVES - 1) / WAVES * WAVES;
       depth = want < WAVES ? WAVES : (want > nmax ? nmax : want);
     }
-    if (any_commit) stage = 0;
-    else { done += committed; }                 // (n is unchanged)
+    // A committed step that changes reductions of its neighbours is evaluated a second time (stage 0).  When none does, the
+    // lists and slots change right here: nothing between barrier (3) and the next round's barrier (1) reads them (the commit
+    // decision above works on the reports alone).
+    if (any_apply) stage = 0;                   // (my_commit of the steps without such neighbours: they just skip the pass)
+    else {
+      if (any_commit && my_commit) deep_mutate(c, r, n);
+      my_commit = false;
+      done += committed;
+      n = cur_n;
+    }
     } else {
       // ---- D: the committed changes (stage 0; their neighbours' reductions were written just above)
       __syncthreads();                          // (4) every reduction is written before a list or a slot changes
       DPH(10);
-      if (my_commit) {
-        int ci, cj;
-        if (r.has_rem && r.has_add) {
-          const int c0 = cell_index(c, r.rx, r.ry, &ci, &cj), c1 = cell_index(c, r.ax, r.ay, &ci, &cj);
-          if (c0 != c1) { cell_remove_1(c, c0, r.tslot); cell_insert_1(c, c1, r.tslot); }
-          write_slot_1(c, r.tslot, r);
-        } else if (r.has_rem) {
-          cell_remove_1(c, cell_index(c, r.rx, r.ry, &ci, &cj), r.tslot);
-          const unsigned short last = L.order[n - 1];
-          L.order[n - 1] = (unsigned short)r.tslot;
-          L.order[r.tidx] = last;
-        } else {
-          const int slot = L.order[n];
-          cell_insert_1(c, cell_index(c, r.ax, r.ay, &ci, &cj), slot);
-          write_slot_1(c, slot, r);
-        }
-      }
+      if (my_commit) deep_mutate(c, r, n);
       my_commit = false;
       done += committed;
       n = cur_n;
@@ -917,12 +1021,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     c.t.px[i] = xy & 0xffff; c.t.py[i] = (xy >> 16) & 0xffff;
     c.t.ps[i] = L.s[slot]; c.t.pr[i] = L.r[slot]; c.t.pa[i] = L.a[slot];
   }
+#ifdef MPP_DEEP_PROF
+  if (stats && c.lane == 0) for (int i = 0; i < DPH_N; ++i) atomicAdd(stats + 16 + DPH_N * c.wave + i, dph_[i]);
+#endif
   if (tid == 0) {
     *c.t.n = n; *c.t.err = err; *c.t.step = step0 + done;
     *c.t.T = D.tring[(int)(done & (long long)rmask)];
-#ifdef MPP_DEEP_PROF
-    if (stats) for (int i = 0; i < 12; ++i) atomicAdd(stats + 4 + i, dph_[i]);
-#endif
     if (stats) { atomicAdd(stats, st_rounds); atomicAdd(stats + 1, st_eval); atomicAdd(stats + 2, st_apply); atomicAdd(stats + 3, (unsigned long long)done); }
   }
 }

@@ -30,10 +30,13 @@ def run(tile, objects, iters, spec, deep, fixed, reps, ntiles=1, cap=1024, repli
         ms.append(ctx.last_kernel_ms())
     st = ctx.deep_stats() if deep else {}
     if deep and os.environ.get("MPP_LIB_PATH", "").endswith("dprof.so"):
-        names = ["A:types", "A:bar1", "A:sort+bar2", "B:draw", "B:pre", "E:eval_delta", "B:post", "bar3", "C:decide+trace+ring", "D:apply-eval",
-                 "D:bar4", "D:mutate"]
-        ph = [ctx.get_option(f"deep_stat{4 + i}") for i in range(12)]
-        st["phase_cycles_per_round_wave0"] = {k: round(v / max(1, st["rounds"])) for k, v in zip(names, ph)}
+        names = ["A:types", "A:bar1", "A:sort+bar2", "B:draw", "B:pre", "E:delta(total)", "B:post", "bar3", "C:decide+trace+ring", "D:apply-delta",
+                 "D:bar4", "D:mutate", "e:tasks", "e:append", "e:load", "e:overlap", "e:pairs+rescan", "e:combine"]
+        R = max(1, st["rounds"])
+        st["phase_cycles_per_round"] = {}
+        for w in range(spec):
+            ph = [ctx.get_option(f"deep_stat{16 + 24 * w + i}") for i in range(len(names))]
+            st["phase_cycles_per_round"][f"wave{w}"] = {k: round(v / R) for k, v in zip(names, ph)}
     pts = ctx.get_points(0)
     return {"spec": spec, "deep": deep, "fixed": fixed, "kernel_ms": min(ms), "proposals_per_s": n_chains * iters / (min(ms) * 1e-3),
             "stats": st, "committed_per_round": (st["committed"] / st["rounds"]) if st.get("rounds") else None,

@@ -17,8 +17,8 @@ def deep_case(tile, n_obj, setup_name, spec, deep, fixed=0, **kw):
     return t, o, ctx
 
 
-@pytest.mark.parametrize("spec,deep,fixed", [(1, 64, 0), (1, 64, 64), (1, 8, 8), (2, 128, 0), (4, 256, 32), (8, 512, 0),
-                                             (8, 512, 512), (8, 64, 8), (8, 128, 96)])
+@pytest.mark.parametrize("spec,deep,fixed", [(1, 64, 0), (1, 64, 64), (1, 8, 8), (2, 128, 0), (4, 256, 32), (8, 256, 0),
+                                             (8, 256, 256), (8, 64, 8), (8, 128, 96)])
 @pytest.mark.parametrize("setup_name", ["legacy", "no-calibration"])
 def test_deep_rounds_reproduce_the_sequential_chain(spec, deep, fixed, setup_name):
     n_steps, seed = 8000, 7
@@ -47,7 +47,7 @@ def test_deep_rounds_reproduce_the_sequential_chain(spec, deep, fixed, setup_nam
 
 def test_deep_chain_matches_oracle():
     n_steps, seed = 12000, 99
-    t, o, ctx = deep_case(160, 60, "legacy", 8, 512, tile_id=3)
+    t, o, ctx = deep_case(160, 60, "legacy", 8, 256, tile_id=3)
     o.set_temperature(1.0, 0.999, 0.0)
     ctx.set_schedule(1.0, 0.999, 0.0)
     oout, oprops = o.run(n_steps, seed, chain=0, trace=True)
