@@ -129,7 +129,13 @@ int mpp_set_stream(mpp_ctx *ctx, void *hip_stream);
 int mpp_synchronize(mpp_ctx *ctx);
 /* "spec_waves": proposals evaluated speculatively per round, one wave each (1 = strictly one at a
  * time); "spec_lanes" (0 = off): lane mode, 4 waves of which `v` lanes each evaluate one step on
- * their own, 4*v steps per round (overrides spec_waves).  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per
+ * their own, 4*v steps per round (overrides spec_waves); "deep" (default 128; 0 = off; a power of two in 8..256): deep
+ * rounds -- every LANE of the chain's spec_waves waves evaluates one step, up to `v` (at most 64 * spec_waves) steps per
+ * round, the steps sorted by kernel type across the workgroup, neighbour energies evaluated by the whole wave for all its
+ * steps at once (csrc/mpp_deep.hip); used for chains drawn from Philox under the shipped energy setups (overlap / max +
+ * alignment / min pair terms, no split / merge, no classic image energy), others run one wave per step as before;
+ * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; read-only "deep_stat0".."deep_stat3":
+ * rounds, steps evaluated, rounds with a second pass, steps committed by the last mpp_run.  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per
  * 32-px cell, at most 64), "auto_grow" (default 1): a chain that would exceed either capacity stops BEFORE that step and
  * mpp_run / mpp_replay double the capacity (while the chain still fits the 160 KB of LDS) and continue it -- the reference's
  * point set has no capacity (point_set/point_set.py:45-188); with 0 the call fails with -11 / -12 and the chain can be

@@ -79,9 +79,9 @@ struct mpp_ctx {
   bool box_dirty = true;
   int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
   // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
-  // (0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
+  // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
-  int deep = 0, deep_fixed = 0;
+  int deep = 128, deep_fixed = 0;
   unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
@@ -307,8 +307,15 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
     int ncell = c->hp.nx * c->hp.ny;
     int spec = c->lanes > 0 ? 4 * c->lanes : c->spec;
     int rb = (c->lanes > 0 && c->H <= 1024) ? c->H + 1 : 0;
-    return (int64_t)(mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec) +
-                     mpp_chain_static_lds_bytes(c->lanes > 0 ? 4 : c->spec));
+    size_t b = mpp_chain_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, spec, rb, c->lanes > 0 ? 4 : c->spec) +
+               mpp_chain_static_lds_bytes(c->lanes > 0 ? 4 : c->spec);
+    if (c->deep > 0 && c->lanes == 0 && c->spec <= 8) {        // deep rounds: at least the smallest round has to fit
+      const int rbd = c->H <= 1024 ? c->H + 1 : 0;
+      const size_t d = mpp_deep_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, rbd, c->spec, c->spec > 8 ? c->spec : 8) +
+                       mpp_deep_static_lds_bytes(c->spec);
+      if (d > b) b = d;
+    }
+    return (int64_t)b;
   }
   return -1;
 }

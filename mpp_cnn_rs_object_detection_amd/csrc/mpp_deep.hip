@@ -49,9 +49,15 @@
 #define DI_ACC (1 << 21)
 #define DI_FULL (1 << 22)    // the cell the step adds to is full (capacity check, made against the round's start state)
 #define DI_NB (1 << 23)      // the step changes cached reductions of neighbours: committing it needs the second pass
+#define DI_NBOV (1 << 24)    // ... of more than two neighbours (their positions are not all reported)
+#define DI_NB2 (1 << 26)     // ... of at least two neighbours
+#define DI_RESC (1 << 25)    // the evaluation re-reduced a neighbour: it looked two interaction ranges away
 
 struct DeepLds {
-  int *info;                   // [nmax][3]: flags | slot, removed xy, added xy -- indexed by the step's offset in the round
+  uint4 *info;                 // [nmax] (flags | slot, removed xy, added xy, cell coordinates) -- indexed by the step's offset in the round
+  uint2 *nb;                   // [nmax] positions of the (at most two) neighbours whose cached reductions the step changes
+  double *st;                  // [nmax][5] ... and their new reductions (2 x 2 values, then the two slots as bits): a step that
+                               // commits writes them; only a step that changes more than two neighbours needs a second pass
   uint4 *pw;                   // [nmax] Philox block 0 of the steps, in sorted order
   unsigned short *poff;        // [nmax] sorted position -> offset of the step in the round
   unsigned short *tcnt;        // [WAVES][16] steps of each kernel type per wave
@@ -61,7 +67,7 @@ struct DeepLds {
   unsigned char *ltab;         // [WAVES][64] the lanes that lead a step, in lane order
 };
 __host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
-  return (size_t)nmax * 16 + (size_t)2 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 12 +
+  return (size_t)nmax * 16 + (size_t)2 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
          (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 64 + 64;
 }
 __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
@@ -73,7 +79,9 @@ __device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
   D.tring = (double *)base; base += (size_t)2 * nmax * 8;
   D.racc = (unsigned long long *)base; base += (size_t)waves * 2 * 64 * 8;
   D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
-  D.info = (int *)base; base += (size_t)nmax * 12;
+  D.info = (uint4 *)base; base += (size_t)nmax * 16;
+  D.nb = (uint2 *)base; base += (size_t)nmax * 8;
+  D.st = (double *)base; base += (size_t)nmax * 40;
   D.poff = (unsigned short *)base; base += (size_t)nmax * 2;
   D.tcnt = (unsigned short *)base; base += (size_t)waves * 16 * 2;
   D.ltab = base;
@@ -250,7 +258,7 @@ __device__ __forceinline__ double clip_area_groups(const Chain &c, bool gact, co
 __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, bool lead, bool has_rem, bool has_add, int rem,
                                            int rxy, int axy, double a_s, double a_r, double a_a, double a_hl, double a_hw,
                                            double a_ca, double a_sa, double a_rad, bool apply, double *sum_out, double *ra0_out,
-                                           double *ra1_out, int *nchg_out DPH_ARGS) {
+                                           double *ra1_out, int *nchg_out, int *nb0_out, int *nb1_out, int *nresc_out, int *su_out, double *sv_out DPH_ARGS) {
   const Lds &L = c.L;
   unsigned int *clist = D.clist + (size_t)c.wave * DEEP_CLIST;
   unsigned long long *racc = D.racc + (size_t)c.wave * 128;
@@ -265,7 +273,8 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   racc[c.lane] = 0ull; racc[64 + c.lane] = 0ull;
   wave_lds_fence();
   double sum = 0.0;
-  int nchg = 0, M = 0, t0 = 0;
+  int nchg = 0, M = 0, t0 = 0, nb0 = 0, nb1 = 0, nresc = 0, su = 0;
+  double sv00 = 0.0, sv01 = 0.0, sv10 = 0.0, sv11 = 0.0;       // new reductions of the first two neighbours that change
   bool pending = false;
   int p_cnt = 0, p_base = 0, p_i = 0;
   unsigned long long p_mask = 0ull;
@@ -447,6 +456,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
           rm &= rm - 1;
           const bool need0 = __builtin_amdgcn_readlane((int)resc0, src) != 0, need1 = __builtin_amdgcn_readlane((int)resc1, src) != 0;
           const int us = __builtin_amdgcn_readlane(u, src), is = __builtin_amdgcn_readlane(i, src);
+          if (c.lane == is) nresc += 1;
           const int rem_s = __builtin_amdgcn_readlane(srem, src);              // (the neighbour lost a removed point: has_rem)
           const bool ha_s = __builtin_amdgcn_readlane((int)s_ha, src) != 0;
           Geo2 bu, ba;                                       // the neighbour and its step's added rectangle, wave-uniform
@@ -584,7 +594,15 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
           cm &= cm - 1;
           const int is = __builtin_amdgcn_readlane(i, src);
           const double v = readlane_d(de, src);
-          if (c.lane == is) { sum += v; nchg += 1; }
+          const int uxy = __builtin_amdgcn_readlane((gu.g.x & 0xffff) | (gu.g.y << 16), src);
+          const int uu = __builtin_amdgcn_readlane(u, src);
+          const double w0 = readlane_d(nv0, src), w1 = readlane_d(nv1, src);
+          if (c.lane == is) {
+            sum += v;
+            if (nchg == 0) { nb0 = uxy; su = uu; sv00 = w0; sv01 = w1; }
+            else if (nchg == 1) { nb1 = uxy; su |= uu << 16; sv10 = w0; sv11 = w1; }
+            nchg += 1;
+          }
         }
         DPH(17);
       }
@@ -594,15 +612,21 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
     if (final) break;
   }
   wave_lds_fence();
-  *sum_out = sum; *nchg_out = nchg;
+  *sum_out = sum; *nchg_out = nchg; *nb0_out = nb0; *nb1_out = nb1; *nresc_out = nresc;
+  *su_out = su; sv_out[0] = sv00; sv_out[1] = sv01; sv_out[2] = sv10; sv_out[3] = sv11;
   *ra0_out = __longlong_as_double((long long)racc[c.lane]);
   *ra1_out = __longlong_as_double((long long)racc[64 + c.lane]);
 }
 
 // the state change of a committed step, done by the lane that evaluated it (n: the population at the round's start)
-__device__ __forceinline__ void deep_mutate(const Chain &c, const Rec &r, int n) {
+__device__ __forceinline__ void deep_mutate(const Chain &c, const Rec &r, int n, const double *st) {
   const Lds &L = c.L;
   int ci, cj;
+  if (r.n_stash > 0 && r.n_stash <= 2) {               // the neighbours whose reductions change (more: the second pass wrote them)
+    const int su = (int)__double_as_longlong(st[4]);
+    L.red0[su & 0xffff] = st[0]; L.red1[su & 0xffff] = st[1];
+    if (r.n_stash == 2) { L.red0[(su >> 16) & 0xffff] = st[2]; L.red1[(su >> 16) & 0xffff] = st[3]; }
+  }
   if (r.has_rem && r.has_add) {                        // move / transform: same slot
     const int c0 = cell_index(c, r.rx, r.ry, &ci, &cj), c1 = cell_index(c, r.ax, r.ay, &ci, &cj);
     if (c0 != c1) { cell_remove_1(c, c0, r.tslot); cell_insert_1(c, c1, r.tslot); }
@@ -725,10 +749,10 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r._pad = 0; r.tslot = -1; r.tidx = -1;
   r.ax = r.ay = r.rx = r.ry = 0; r.as = r.ar = r.aa = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0; r.lin_a = 0.0; r.gate_a = 1;
   bool mine = false, my_commit = false;
-  int myoff = 0, lim = 0, committed = 0, cur_n = n;
+  int myoff = 0, lim = 0, committed = 0, cur_n = n, nb0 = 0, nb1 = 0;
   double Tm = 0.0;
   while (stage == 0 || (done < n_steps && err == 0)) {
-    bool do_eval = my_commit && r.n_stash > 0;  // stage 0: the steps that commit and change reductions of neighbours
+    bool do_eval = my_commit && r.n_stash > 2;  // stage 0: the steps that commit and change more neighbours than they could note
     DPH_T0();
     if (stage == 1) {
     int N = fixed_depth > 0 ? fixed_depth : depth;
@@ -813,16 +837,20 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     // ---- the neighbours' part of dE (energy_graph.py:139-225) for all steps of the wave; stage 0 writes their cached
     //      reductions
     {
-      double ra0 = 0.0, ra1 = 0.0, sde = 0.0;
-      int ns = 0;
+      double ra0 = 0.0, ra1 = 0.0, sde = 0.0, sv[4];
+      int ns = 0, nresc = 0, su = 0;
       const bool hr = r.has_rem != 0, ha = r.has_add != 0;
       deep_delta(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
-                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns DPH_PASS);
+                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns, &nb0, &nb1, &nresc, &su, sv DPH_PASS);
       if (stage == 1 && do_eval) {
         double dE = sde;
         if (ha) dE += finish_energy_c(c, r.lin_a + pair_part_c(c, r.gate_a, ra0, ra1));
         if (hr) dE -= finish_energy_c(c, L.lin[r.tslot] + pair_part_c(c, (int)L.gate[r.tslot], L.red0[r.tslot], L.red1[r.tslot]));
-        r.dE = dE; r.ra0 = ra0; r.ra1 = ra1; r.n_stash = ns;
+        r.dE = dE; r.ra0 = ra0; r.ra1 = ra1; r.n_stash = ns; r._pad2 = nresc;
+        if (ns > 0 && ns <= 2) {                 // (kept for the commit: written by this lane again, read by no other)
+          double *st = D.st + (size_t)5 * myoff;
+          st[0] = sv[0]; st[1] = sv[1]; st[2] = sv[2]; st[3] = sv[3]; st[4] = __longlong_as_double((long long)su);
+        }
       }
     }
     DPH(stage == 1 ? 5 : 9);
@@ -842,35 +870,45 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
         const int c1 = cell_index(c, r.ax, r.ay, &ci, &cj), c0 = r.has_rem ? cell_index(c, r.rx, r.ry, &ci, &cj) : -1;
         full = c1 != c0 && (int)L.cell_cnt[c1] >= c.h.cell_cap;
       }
-      int f = (r.tslot & 0xffff) | (r.valid ? DI_VALID : DI_BAD) | (chg ? DI_CHG : 0) | (r.has_rem ? DI_HR : 0) |
-              (r.has_add ? DI_HA : 0) | (r.accepted ? DI_ACC : 0) | (full ? DI_FULL : 0) | (chg && r.n_stash > 0 ? DI_NB : 0);
-      D.info[3 * myoff] = f;
-      D.info[3 * myoff + 1] = (r.rx & 0xffff) | (r.ry << 16);
-      D.info[3 * myoff + 2] = (r.ax & 0xffff) | (r.ay << 16);
+      int ci_r = 0, cj_r = 0, ci_a = 0, cj_a = 0;
+      if (r.has_rem) cell_index(c, r.rx, r.ry, &ci_r, &cj_r);
+      if (r.has_add) cell_index(c, r.ax, r.ay, &ci_a, &cj_a);
+      const int f = (r.tslot & 0xffff) | (r.valid ? DI_VALID : DI_BAD) | (chg ? DI_CHG : 0) | (r.has_rem ? DI_HR : 0) |
+                    (r.has_add ? DI_HA : 0) | (r.accepted ? DI_ACC : 0) | (full ? DI_FULL : 0) | (chg && r.n_stash > 0 ? DI_NB : 0) |
+                    (chg && r.n_stash > 1 ? DI_NB2 : 0) | (chg && r.n_stash > 2 ? DI_NBOV : 0) | (r.valid && r._pad2 > 0 ? DI_RESC : 0);
+      D.info[myoff] = make_uint4((unsigned)f, (unsigned)((r.rx & 0xffff) | (r.ry << 16)), (unsigned)((r.ax & 0xffff) | (r.ay << 16)),
+                                 (unsigned)(ci_r | (cj_r << 8) | (ci_a << 16) | (cj_a << 24)));
+      if (chg) D.nb[myoff] = make_uint2((unsigned)nb0, (unsigned)nb1);
     }
     DPH(6);
     __syncthreads();                            // (3)
     DPH(7);
 
-    // ---- C: which steps commit (every wave takes the same decision from the same reports)
-    int f_[NCH], pr_[NCH], pa_[NCH];
+    // ---- C: which steps commit (every wave takes the same decision from the same reports).  Steps commit in order.  A
+    //      committed move / transform q makes a later report o untrustworthy when o read something q writes:
+    //      the slot itself; a rectangle within the interaction range of o's points, before or after (q's slot);
+    //      a neighbour whose cached reductions q changes and o used (q reports up to two of them; more: twice the range);
+    //      a cell list of o's 3 x 3 blocks (q crosses a cell border: the order of that cell's entries changes);
+    //      and, when o re-reduced a neighbour, anything within twice the range.  A birth / death ends the round.
+    uint4 o_[NCH];
     bool ok_[NCH];
     unsigned long long am_[NCH], cm_[NCH];
     const int nch = (lim + 63) >> 6;            // chunks in use
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      f_[ch] = 0; pr_[ch] = 0; pa_[ch] = 0; ok_[ch] = false; am_[ch] = 0ull; cm_[ch] = 0ull;
+      o_[ch] = make_uint4(0u, 0u, 0u, 0u); ok_[ch] = false; am_[ch] = 0ull; cm_[ch] = 0ull;
       if (ch < nch) {
         const int idx = ch * 64 + c.lane;
         const bool in = idx < lim;
-        f_[ch] = in ? D.info[3 * idx] : 0; pr_[ch] = in ? D.info[3 * idx + 1] : 0; pa_[ch] = in ? D.info[3 * idx + 2] : 0;
-        ok_[ch] = in && (f_[ch] & DI_VALID);
-        am_[ch] = __ballot(in && (f_[ch] & DI_CHG));
+        if (in) o_[ch] = D.info[idx];
+        ok_[ch] = in && (o_[ch].x & DI_VALID);
+        am_[ch] = __ballot(in && (o_[ch].x & DI_CHG));
       }
     }
     int cur = 0;
     committed = 0; cur_n = n;
     bool any_commit = false, any_apply = false;     // a step commits with a change; ... and changes reductions of neighbours
+    const int range2 = c.pr0.maxd2 > c.pr1.maxd2 ? c.pr0.maxd2 : c.pr1.maxd2, far2 = P->conflict_d2;
     while (true) {
       int first_bad = lim;
 #pragma unroll
@@ -888,26 +926,13 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
         }
       if (wq < 0) {
         committed = first_bad;
-        if (first_bad < lim) {
-          int fb = 0;
-#pragma unroll
-          for (int ch = 0; ch < NCH; ++ch) if ((first_bad >> 6) == ch) fb = __builtin_amdgcn_readlane(f_[ch], first_bad & 63);
-          if (fb & DI_BAD) err = ERR_BAD_TARGET;
-          // otherwise: invalidated by an earlier commit of this round -> evaluated again next round
-        }
+        if (first_bad < lim && (D.info[first_bad].x & DI_BAD)) err = ERR_BAD_TARGET;
+        // otherwise: invalidated by an earlier commit of this round -> evaluated again next round
         break;
       }
-      int qf = 0, qr = 0, qa = 0;
-#pragma unroll
-      for (int ch = 0; ch < NCH; ++ch)
-        if ((wq >> 6) == ch) {
-          qf = __builtin_amdgcn_readlane(f_[ch], wq & 63); qr = __builtin_amdgcn_readlane(pr_[ch], wq & 63);
-          qa = __builtin_amdgcn_readlane(pa_[ch], wq & 63);
-        }
+      const uint4 q = D.info[wq];                          // (one address for the wave: a broadcast read)
+      const int qf = (int)q.x;
       const bool q_hr = qf & DI_HR, q_ha = qf & DI_HA;
-      const int q_ts = qf & 0xffff, qrx = qr & 0xffff, qry = (qr >> 16) & 0xffff, qax = qa & 0xffff, qay = (qa >> 16) & 0xffff;
-      int ci, cj;
-      const int q_cr = q_hr ? cell_index(c, qrx, qry, &ci, &cj) : -1, q_ca = q_ha ? cell_index(c, qax, qay, &ci, &cj) : -2;
       // capacity checks BEFORE anything of the step is applied: the chain stops in the state before it (see mpp_sampler.hip)
       // (the evaluating lane looked at the cell's count: no state is read here, see "stage")
       if (qf & DI_FULL) { err = ERR_CELL_OVERFLOW; committed = wq; break; }
@@ -918,35 +943,54 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
         any_commit = true;
-        if (qf & DI_NB) any_apply = true;
+        if (qf & DI_NBOV) any_apply = true;
         committed = wq + 1;
         break;
       }
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) if ((wq >> 6) == ch) cm_[ch] |= 1ull << (wq & 63);
       any_commit = true;
-      if (qf & DI_NB) any_apply = true;
+      if (qf & DI_NBOV) any_apply = true;
       // is a later report still trustworthy after this move / transform?
+      const int q_ts = qf & 0xffff;
+      const int qx[2] = {(int)(q.y & 0xffffu), (int)(q.z & 0xffffu)}, qy[2] = {(int)(q.y >> 16), (int)(q.z >> 16)};
+      const int qci[2] = {(int)(q.w & 0xffu), (int)((q.w >> 16) & 0xffu)}, qcj[2] = {(int)((q.w >> 8) & 0xffu), (int)(q.w >> 24)};
+      const bool q_cross = qci[0] != qci[1] || qcj[0] != qcj[1];
+      const bool q_far = (qf & DI_NBOV) != 0;
+      int qnx[2] = {0, 0}, qny[2] = {0, 0}, q_nnb = 0;
+      if (qf & DI_NB) {
+        const uint2 qn = D.nb[wq];
+        qnx[0] = (int)(qn.x & 0xffffu); qny[0] = (int)(qn.x >> 16); qnx[1] = (int)(qn.y & 0xffffu); qny[1] = (int)(qn.y >> 16);
+        q_nnb = 1;
+      }
+      const bool q_nb2 = (qf & DI_NB2) != 0;
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const int idx = ch * 64 + c.lane;
         if (ch < nch && ch * 64 + 63 > wq && idx > wq && ok_[ch]) {
-          const int mf = f_[ch];
-          const bool m_hr = mf & DI_HR, m_ha = mf & DI_HA;
-          const int mrx = pr_[ch] & 0xffff, mry = (pr_[ch] >> 16) & 0xffff, max_ = pa_[ch] & 0xffff, may = (pa_[ch] >> 16) & 0xffff;
-          const int m_cr = m_hr ? cell_index(c, mrx, mry, &ci, &cj) : -1, m_ca = m_ha ? cell_index(c, max_, may, &ci, &cj) : -2;
-          bool bad = (m_hr && (mf & 0xffff) == q_ts) || m_cr == q_cr || m_cr == q_ca || m_ca == q_cr || m_ca == q_ca;
-          const int ox[2] = {mrx, max_}, oy[2] = {mry, may};
-          const bool oh[2] = {m_hr, m_ha};
-          const int qx[2] = {qrx, qax}, qy[2] = {qry, qay};
+          const uint4 o = o_[ch];
+          const int of = (int)o.x;
+          const bool oh[2] = {(of & DI_HR) != 0, (of & DI_HA) != 0};
+          const int ox[2] = {(int)(o.y & 0xffffu), (int)(o.z & 0xffffu)}, oy[2] = {(int)(o.y >> 16), (int)(o.z >> 16)};
+          const int oci[2] = {(int)(o.w & 0xffu), (int)((o.w >> 16) & 0xffu)}, ocj[2] = {(int)((o.w >> 8) & 0xffu), (int)(o.w >> 24)};
+          const int lim2 = ((of & (DI_RESC | DI_NBOV)) || q_far) ? far2 : range2;
+          bool bad = oh[0] && (of & 0xffff) == q_ts;
 #pragma unroll
           for (int a = 0; a < 2; ++a)
+            if (oh[a]) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-              if (oh[a]) {
+              for (int b = 0; b < 2; ++b) {
                 const int dx = ox[a] - qx[b], dy = oy[a] - qy[b];
-                if (dx * dx + dy * dy <= P->conflict_d2) bad = true;
+                if (dx * dx + dy * dy <= lim2) bad = true;
+                if (q_cross && abs(oci[a] - qci[b]) <= 1 && abs(ocj[a] - qcj[b]) <= 1) bad = true;
               }
+              if (q_nnb > 0) {
+                const int dx0 = ox[a] - qnx[0], dy0 = oy[a] - qny[0];
+                if (dx0 * dx0 + dy0 * dy0 <= range2) bad = true;
+                const int dx1 = ox[a] - qnx[1], dy1 = oy[a] - qny[1];
+                if (q_nb2 && dx1 * dx1 + dy1 * dy1 <= range2) bad = true;
+              }
+            }
           if (bad) ok_[ch] = false;
         }
       }
@@ -996,7 +1040,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     // decision above works on the reports alone).
     if (any_apply) stage = 0;                   // (my_commit of the steps without such neighbours: they just skip the pass)
     else {
-      if (any_commit && my_commit) deep_mutate(c, r, n);
+      if (any_commit && my_commit) deep_mutate(c, r, n, D.st + (size_t)5 * myoff);
       my_commit = false;
       done += committed;
       n = cur_n;
@@ -1005,7 +1049,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       // ---- D: the committed changes (stage 0; their neighbours' reductions were written just above)
       __syncthreads();                          // (4) every reduction is written before a list or a slot changes
       DPH(10);
-      if (my_commit) deep_mutate(c, r, n);
+      if (my_commit) deep_mutate(c, r, n, D.st + (size_t)5 * myoff);
       my_commit = false;
       done += committed;
       n = cur_n;

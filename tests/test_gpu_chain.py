@@ -13,7 +13,8 @@ from mpp_cnn_rs_object_detection_amd import hip_api, kernels, mappings, synth
 pytestmark = pytest.mark.gpu
 
 
-def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, lanes=0, split_merge=False):
+def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, lanes=0, split_merge=False, deep=0):
+    """`deep` = 0: the one-wave-per-step kernels these tests were written for (deep rounds: tests/test_gpu_deep.py)"""
     t = synth.make_tile(tile, n_obj, tile_id=tile_id, noise=noise)
     setup, comb, model = model_for(setup_name)
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kernels.make_kernels(mappings.default_mappings(), 1.0))
@@ -21,7 +22,7 @@ def setup_case(tile, n_obj, setup_name, tile_id=0, noise=0.1, spec=1, cap=512, l
     kd = kernels.make_kernels(mappings.default_mappings(), max(1, len(xy)), use_split_merge=split_merge)
     o = oracle.Oracle(t.shape, t.det, t.marks, model, kd)
     o.set_points(xy, marks)
-    ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec, spec_lanes=lanes)
+    ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec, spec_lanes=lanes, deep=deep)
     ctx.set_maps(t.det, t.marks)
     ctx.set_model(model, mappings.default_mappings())
     ctx.set_kernels(kd)
