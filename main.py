@@ -4,9 +4,10 @@
     python main.py -p infer -m mpp -c mpp_hrcM [-d DATASET] [-o]
 
 ``-m mpp`` runs the MI355X sampler; ``-m posnet`` / ``-m shapenet`` with ``-p infer`` write the score-map
-hand-off pickles the reference's MPP stage reads (``NNNN_results.pkl``).  Training procedures of the
-reference are outside this build.  With ``torchrun --nproc-per-node N`` the tiles of every image are
-dealt to N GPUs and the detections all-gathered (RCCL).
+hand-off pickles the reference's MPP stage reads (``NNNN_results.pkl``).  ``-p train -m mpp`` learns the
+energy weights (manual / ordering / integral criterion) and calibrates; the training loops of the two
+U-Nets are outside this build.  With ``torchrun --nproc-per-node N`` the images of the dataset are
+dealt to N GPUs (one gather of the results at the end; RCCL).
 """
 import argparse
 import json

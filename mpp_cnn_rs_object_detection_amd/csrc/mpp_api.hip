@@ -21,7 +21,7 @@ extern "C" size_t mpp_deep_static_lds_bytes(int waves);
 extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
-                                      mpp_proposal *props, int nmax, int fixed_depth, unsigned long long *stats);
+                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats);
 extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -81,7 +81,7 @@ struct mpp_ctx {
   // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
-  int deep = 128, deep_fixed = 0;
+  int deep = 128, deep_fixed = 0, deep_gain = 16;   // deep_gain / 8 x the steps the last rounds committed = depth of the next
   unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
@@ -248,6 +248,9 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else if (!strcmp(name, "deep")) {
     if (v != 0 && (v < 8 || v > 256 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..256");
     c->deep = (int)v;
+  } else if (!strcmp(name, "deep_gain")) {
+    if (v < 8 || v > 64) return fail(c, -1, "deep_gain must be in 8..64 (eighths)");
+    c->deep_gain = (int)v;
   } else if (!strcmp(name, "deep_fixed")) {
     if (v < 0 || v > 256) return fail(c, -1, "deep_fixed must be in 0..256");
     c->deep_fixed = (int)v;
@@ -973,7 +976,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
       int fixed = c->deep_fixed > nmax ? nmax : c->deep_fixed;
       if (fixed > 0) { fixed = fixed / c->spec * c->spec; if (fixed < c->spec) fixed = c->spec; }
       HIPCHK(c, mpp_launch_deep(c->stream, c->spec, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed, chain0,
-                                trace_tile, d_out, d_props, nmax, fixed, c->deep_stats));
+                                trace_tile, d_out, d_props, nmax, fixed, c->deep_gain, c->deep_stats));
     } else
     HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed,
                                chain0, d_tape, trace_tile, d_out, d_props));

@@ -1033,12 +1033,19 @@ __device__ int count_le_8ary(int n, F key_le) {
     hi = c < 7 ? lo + (c + 1) * step - 1 : hi;
     lo = nlo;
   }
+  // the last (at most 8) entries: probed together -- one memory latency instead of one per entry (key_le of an index
+  // beyond hi is never counted; the probe is clamped so that it reads inside the table)
   int c = lo;
-  for (int i = lo; i < hi; ++i) c += key_le(i) ? 1 : 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int i = lo + j < hi ? lo + j : (hi > 0 ? hi - 1 : 0);
+    const bool le = key_le(i);
+    c += (lo + j < hi && le) ? 1 : 0;
+  }
   return c;
 }
 
-__device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex, int *ey) {
+__device__ __forceinline__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex, int *ey) {
   const DevParams *P = c.P;
   const int md = P->kern.max_delta;
   const int x0 = max(0, x - md), x1 = min(x + md + 1, c.h.H), y0 = max(0, y - md), y1 = min(y + md + 1, c.h.W);
@@ -1047,6 +1054,36 @@ __device__ void window_draw_lane(const Chain &c, int x, int y, double u, int *ex
   double before = 0.0;
   const double thr = u * tot;
   int row = 0;
+  if (nrow <= 17 && wc <= 17) {
+    // the usual window (max_delta <= 8): the segment sums of all rows are requested together -- two memory latencies for
+    // the row, one for the column, instead of two per row walked -- and added in the order of the walk below
+    double seg[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+      const int xi = x0 + (i < nrow ? i : nrow - 1);
+      const MPP_GLOBAL double *rp = c.t.rowpart + (size_t)xi * c.h.W;
+      const double hi_ = rp[y1 - 1], lo_ = y0 > 0 ? rp[y0 - 1] : 0.0;
+      seg[i] = hi_ - lo_;
+    }
+    bool go = true;
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+      const double nxt = before + seg[i];
+      go = go && i < nrow && nxt <= thr && i < nrow - 1;
+      if (go) { before = nxt; row = i + 1; }
+    }
+    const MPP_GLOBAL double *rp = c.t.rowpart + (size_t)(x0 + row) * c.h.W;
+    const double lead = y0 > 0 ? rp[y0 - 1] : 0.0;
+    double cv[17];
+#pragma unroll
+    for (int jj = 0; jj < 17; ++jj) cv[jj] = rp[y0 + (jj < wc ? jj : wc - 1)];
+    int col = 0;
+#pragma unroll
+    for (int jj = 0; jj < 17; ++jj) col += (jj < wc && (before + (cv[jj] - lead)) <= thr) ? 1 : 0;
+    if (col >= wc) col = wc - 1;
+    *ex = x0 + row; *ey = y0 + col;
+    return;
+  }
   for (int i = 0; i < nrow; ++i) {
     const double *rp = c.t.rowpart + (size_t)(x0 + i) * c.h.W;
     double nxt = before + (rp[y1 - 1] - (y0 > 0 ? rp[y0 - 1] : 0.0));
@@ -1122,7 +1159,7 @@ __device__ __forceinline__ int draw_head(const Chain &c, const uint32_t w[8], Re
 // it shares the SIMD with -- but the split itself gained 1.4 % on one tile and 3.2 % with 4 096 chains; a real call
 // (noinline) costs a third of the speed.  DESIGN.md 6.)
 template <bool LANE>
-__device__ void draw_birth(const Chain &c, const uint32_t w[8], int k, Rec &r, int *keep, MapVals *pmv) {
+__device__ __forceinline__ void draw_birth(const Chain &c, const uint32_t w[8], int k, Rec &r, int *keep, MapVals *pmv) {
   const DevParams *P = c.P;
   if (k == MPP_K_UBIRTH) {
     r.has_add = 1;
@@ -1226,7 +1263,7 @@ __device__ void draw_birth(const Chain &c, const uint32_t w[8], int k, Rec &r, i
   }
 }
 template <bool LANE>
-__device__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
+__device__ __forceinline__ void draw_proposal(const Chain &c, const uint32_t w[8], int n, Rec &r, int *keep, uint32_t k0, uint32_t k1,
                               uint64_t step, uint32_t chain, MapVals *pmv) {
   const DevParams *P = c.P;
   const int k = draw_head<LANE>(c, w, r, k0, k1, step, chain);

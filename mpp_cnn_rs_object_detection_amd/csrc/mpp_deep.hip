@@ -61,14 +61,14 @@ struct DeepLds {
   uint4 *pw;                   // [nmax] Philox block 0 of the steps, in sorted order
   unsigned short *poff;        // [nmax] sorted position -> offset of the step in the round
   unsigned short *tcnt;        // [WAVES][16] steps of each kernel type per wave
-  double *tring;               // [2 * nmax] temperature of step (offset & mask)
+  double *tring;               // [4 * nmax] temperature of step (offset & mask), filled two rounds ahead
   unsigned long long *racc;    // [WAVES][2][64] per step of a wave: max of the overlaps / min of the alignments with the added point
   unsigned int *clist;         // [WAVES][DEEP_CLIST] (step << 16 | slot): the neighbours in range of a wave's steps, in order
-  unsigned char *ltab;         // [WAVES][64] the lanes that lead a step, in lane order
+  unsigned char *ltab;         // [WAVES][128] the 3 x 3 blocks of cells a wave's steps look at (lane | 0x80: the added point's)
 };
 __host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
-  return (size_t)nmax * 16 + (size_t)2 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
-         (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 64 + 64;
+  return (size_t)nmax * 16 + (size_t)4 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
+         (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 128 + 64;
 }
 __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
   return (lds_bytes(cap, ncell, cell_cap, 0, rowbase_n, waves) + 15) & ~(size_t)15;
@@ -76,7 +76,7 @@ __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_c
 __device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
   DeepLds D;
   D.pw = (uint4 *)base; base += (size_t)nmax * 16;
-  D.tring = (double *)base; base += (size_t)2 * nmax * 8;
+  D.tring = (double *)base; base += (size_t)4 * nmax * 8;
   D.racc = (unsigned long long *)base; base += (size_t)waves * 2 * 64 * 8;
   D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
   D.info = (uint4 *)base; base += (size_t)nmax * 16;
@@ -245,9 +245,11 @@ __device__ __forceinline__ double clip_area_groups(const Chain &c, bool gact, co
 // mpp_chain.hpp, per neighbour, summed in the same order).  Lane i leads step i (`lead`: it has a point to remove and / or a
 // rectangle to add).  One lane walking the 3 x 3 cells around its own step's points is a chain of dependent LDS reads per
 // cell and entry (78 k cycles a round); here the work of all the wave's steps is dealt to all 64 lanes, twice:
-//   1  the (step, cell) pairs -- 18 per step -- go to the lanes, 64 at a time; a lane looks at its cell's entries, four at a
-//      time, and keeps those within the longest interaction range of the removed or the added point; an exclusive prefix
-//      sum puts them into the wave's candidate list in (step, cell, entry) order -- the order eval_delta sums in;
+//   1  the cells to look at -- the 3 x 3 block around a step's removed point, then, unless it is the same block, the one
+//      around its added point -- go to the lanes, 128 at a time (two neighbouring cells per lane); a lane looks at its
+//      cells' entries, four at a time, and keeps those within the longest interaction range of the removed or the added
+//      point; an exclusive prefix sum puts them into the wave's candidate list in (step, cell, entry) order -- the order
+//      eval_delta sums in;
 //   2  the list goes to the lanes, 64 (step, neighbour) pairs at a time: the neighbour's geometry and cached reductions from
 //      LDS, the step's added rectangle from its leader's registers (ds_bpermute); rectangle clips and the re-reduction of a
 //      neighbour that loses its extremum are done by the whole wave, one after the other, as in eval_delta<FAST>; the few
@@ -266,57 +268,75 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   const int maxd2_0 = c.pr0.maxd2, maxd2_1 = c.pr1.maxd2, range2 = maxd2_0 > maxd2_1 ? maxd2_0 : maxd2_1;
   const double rew = c.pr1.p0 != 0.0 ? 1.0 : 0.0;
   const unsigned long long below = (1ull << c.lane) - 1ull;
-  const unsigned long long leadm = __ballot(lead);
-  const int ntasks = 18 * __popcll(leadm);
-  unsigned char *ltab = D.ltab + (size_t)c.wave * 64;
-  if (lead) ltab[__popcll(leadm & below)] = (unsigned char)c.lane;
+  // the 3 x 3 blocks to look at: around the removed point, then -- unless it is the same block -- around the added one;
+  // ptab lists them in (step, removed before added) order: lane | 0x80 for an added point's block
+  unsigned char *ptab = D.ltab + (size_t)c.wave * 128;
+  int npos = 0, ntasks = 0;
+  {
+    const int rcell_i = cell_coord(c, rxy & 0xffff), rcell_j = cell_coord(c, (rxy >> 16) & 0xffff);
+    const int acell_i = cell_coord(c, axy & 0xffff), acell_j = cell_coord(c, (axy >> 16) & 0xffff);
+    const bool pa_ = lead && has_rem, pb_ = lead && has_add && !(has_rem && rcell_i == acell_i && rcell_j == acell_j);
+    const int cnt_ = (pa_ ? 1 : 0) + (pb_ ? 1 : 0);
+    const int incl = wave_incl_scan(cnt_);
+    int pos = incl - cnt_;
+    if (pa_) ptab[pos++] = (unsigned char)c.lane;
+    if (pb_) ptab[pos] = (unsigned char)(c.lane | 0x80);
+    npos = __builtin_amdgcn_readlane(incl, 63);
+    ntasks = 9 * npos;
+  }
   racc[c.lane] = 0ull; racc[64 + c.lane] = 0ull;
   wave_lds_fence();
   double sum = 0.0;
   int nchg = 0, M = 0, t0 = 0, nb0 = 0, nb1 = 0, nresc = 0, su = 0;
   double sv00 = 0.0, sv01 = 0.0, sv10 = 0.0, sv11 = 0.0;       // new reductions of the first two neighbours that change
   bool pending = false;
-  int p_cnt = 0, p_base = 0, p_i = 0;
-  unsigned long long p_mask = 0ull;
+  int p_cnt = 0, p_base[2] = {0, 0}, p_i[2] = {0, 0};
+  unsigned long long p_mask[2] = {0ull, 0ull};
   for (;;) {
     bool final = false;
     if (__ballot(pending) == 0ull) {
       if (t0 >= ntasks) final = true;
       else {
-        // ---- 1: the next 64 (step, cell) pairs
-        const int t = t0 + c.lane;
-        t0 += WAVE;
-        const int ir = (t * 3641) >> 16, k = t - 18 * ir;          // t / 18, t % 18 (t < 1152)
-        const int i = t < ntasks ? (int)ltab[ir] : 0;               // the lane that leads the task's step
-        const int sfl = __shfl(flags, i, WAVE), srem = __shfl(rem, i, WAVE), srxy = __shfl(rxy, i, WAVE), saxy = __shfl(axy, i, WAVE);
-        const bool s_hr = sfl & 1, s_ha = sfl & 2;
-        const int rx = srxy & 0xffff, ry = (srxy >> 16) & 0xffff, ax = saxy & 0xffff, ay = (saxy >> 16) & 0xffff;
-        const int cir = cell_coord(c, rx), cjr = cell_coord(c, ry), cia = cell_coord(c, ax), cja = cell_coord(c, ay);
-        const bool second = k >= 9;
-        const int kk = second ? k - 9 : k, k3 = (kk * 11) >> 5;    // kk / 3 for kk < 9
-        const int ci = (second ? cia : cir) + k3 - 1, cj = (second ? cja : cjr) + (kk - 3 * k3) - 1;
-        bool ok = t < ntasks && (sfl & 4) && (second ? s_ha : s_hr);
-        if (ok && second && s_hr && abs(ci - cir) <= 1 && abs(cj - cjr) <= 1) ok = false;      // already listed
-        ok = ok && ci >= 0 && ci < c.h.nx && cj >= 0 && cj < c.h.ny;
-        const int cell = ok ? cj + ci * c.h.ny : 0;
-        const int cnt = ok ? (int)L.cell_cnt[cell] : 0;
-        const int base = cell * c.h.cell_cap;
-        unsigned long long mask = 0ull;
-        for (int e0 = 0; __ballot(e0 < cnt) != 0ull; e0 += 4) {
-          int u_[4], xy_[4];
+        // ---- 1: the next 128 (block, cell) pairs, two neighbouring ones per lane
+        p_cnt = 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) u_[q] = e0 + q < cnt ? (int)L.cell_items[base + e0 + q] : 0;
+        for (int q2 = 0; q2 < 2; ++q2) {
+          const int t = t0 + 2 * c.lane + q2;
+          const int ip = (t * 7282) >> 16, k = t - 9 * ip;          // t / 9, t % 9 (t < 1152)
+          const int pe = t < ntasks ? (int)ptab[ip] : 0;            // the block's step and kind
+          const int i = pe & 63;
+          const bool second = (pe & 0x80) != 0;
+          const int sfl = __shfl(flags, i, WAVE), srem = __shfl(rem, i, WAVE), srxy = __shfl(rxy, i, WAVE), saxy = __shfl(axy, i, WAVE);
+          const bool s_hr = sfl & 1, s_ha = sfl & 2;
+          const int rx = srxy & 0xffff, ry = (srxy >> 16) & 0xffff, ax = saxy & 0xffff, ay = (saxy >> 16) & 0xffff;
+          const int cir = cell_coord(c, rx), cjr = cell_coord(c, ry), cia = cell_coord(c, ax), cja = cell_coord(c, ay);
+          const int k3 = (k * 11) >> 5;                              // k / 3 for k < 9
+          const int ci = (second ? cia : cir) + k3 - 1, cj = (second ? cja : cjr) + (k - 3 * k3) - 1;
+          bool ok = t < ntasks;
+          if (ok && second && s_hr && abs(ci - cir) <= 1 && abs(cj - cjr) <= 1) ok = false;      // already listed
+          ok = ok && ci >= 0 && ci < c.h.nx && cj >= 0 && cj < c.h.ny;
+          const int cell = ok ? cj + ci * c.h.ny : 0;
+          const int cnt = ok ? (int)L.cell_cnt[cell] : 0;
+          const int base = cell * c.h.cell_cap;
+          unsigned long long mask = 0ull;
+          for (int e0 = 0; __ballot(e0 < cnt) != 0ull; e0 += 4) {
+            int u_[4], xy_[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) xy_[q] = e0 + q < cnt ? L.xy[u_[q]] : 0;
+            for (int q = 0; q < 4; ++q) u_[q] = e0 + q < cnt ? (int)L.cell_items[base + e0 + q] : 0;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int ux = xy_[q] & 0xffff, uy = (xy_[q] >> 16) & 0xffff;
-            const int dxr = ux - rx, dyr = uy - ry, dxa = ux - ax, dya = uy - ay;
-            const bool inr = (s_hr && dxr * dxr + dyr * dyr <= range2) || (s_ha && dxa * dxa + dya * dya <= range2);
-            if (e0 + q < cnt && u_[q] != (s_hr ? srem : -1) && inr) mask |= 1ull << (e0 + q);
+            for (int q = 0; q < 4; ++q) xy_[q] = e0 + q < cnt ? L.xy[u_[q]] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int ux = xy_[q] & 0xffff, uy = (xy_[q] >> 16) & 0xffff;
+              const int dxr = ux - rx, dyr = uy - ry, dxa = ux - ax, dya = uy - ay;
+              const bool inr = (s_hr && dxr * dxr + dyr * dyr <= range2) || (s_ha && dxa * dxa + dya * dya <= range2);
+              if (e0 + q < cnt && u_[q] != (s_hr ? srem : -1) && inr) mask |= 1ull << (e0 + q);
+            }
           }
+          p_mask[q2] = mask; p_base[q2] = base; p_i[q2] = i;
+          p_cnt += __popcll(mask);
         }
-        p_cnt = __popcll(mask); p_mask = mask; p_base = base; p_i = i;
+        t0 += 2 * WAVE;
         pending = p_cnt > 0;
         DPH(12);
       }
@@ -330,11 +350,14 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
       const unsigned long long fm = __ballot(fit);
       if (fit) {
         int pos = M + incl - c_;
-        unsigned long long m = p_mask;
-        while (m) {
-          const int e = __ffsll((long long)m) - 1;
-          m &= m - 1;
-          clist[pos++] = ((unsigned int)p_i << 16) | (unsigned int)L.cell_items[p_base + e];
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          unsigned long long m = p_mask[q2];
+          while (m) {
+            const int e = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            clist[pos++] = ((unsigned int)p_i[q2] << 16) | (unsigned int)L.cell_items[p_base[q2] + e];
+          }
         }
         pending = false;
       }
@@ -649,7 +672,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
                                                                  const long long *until, long long trace_base,
                                                                  unsigned long long seed, unsigned int chain0, int trace_tile,
                                                                  mpp_step_out *out, mpp_proposal *props, int nmax,
-                                                                 int fixed_depth, unsigned long long *stats) {
+                                                                 int fixed_depth, int gain8, unsigned long long *stats) {
   constexpr int NCH = DEEP_NMAX_LIMIT / 64;              // chunks of 64 step reports a lane may have to look at
   const DevParams *P = deep_stage_params<(WAVES >= MPP_LDS_PARAMS_MIN_WAVES)>(Pv, WAVE * WAVES);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -693,7 +716,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   }
   __syncthreads();
   const double alpha = c.t.T[1], T_target = c.t.T[2];
-  const int rmask = 2 * nmax - 1;
+  const int rmask = 4 * nmax - 1;
   if (tid == 0) {                               // serial: keeps the cell order, hence the result, deterministic
     for (int i = 0; i < n0; ++i) {
       int xy = L.xy[i], ci, cj;
@@ -705,9 +728,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     }
     L.sh[1] = err;
   }
-  if (tid == nthr - 1) {                        // temperatures of the first nmax steps (rjmcmc.py:158-159, one multiply per step)
+  if (tid == nthr - 1) {                        // temperatures of the first 2 * nmax steps (rjmcmc.py:158-159, one multiply per step)
     double Tc = *c.t.T;
-    for (int i = 0; i < nmax; ++i) { D.tring[i] = Tc; if (Tc > T_target) Tc *= alpha; }
+    for (int i = 0; i < 2 * nmax; ++i) { D.tring[i] = Tc; if (Tc > T_target) Tc *= alpha; }
   }
   __syncthreads();
   err = __builtin_amdgcn_readfirstlane(L.sh[1]);
@@ -719,7 +742,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       Geo2 gu = load_geo(L, u);
 #pragma clang loop unroll(disable)
       for (int p = 0; p < P->model.n_pair; ++p) {
-        double v = rescan_lane(c, p, u, gu, -1, false, dummy, dg);
+        double v;
+        [[clang::always_inline]] v = rescan_lane(c, p, u, gu, -1, false, dummy, dg);     // (a real call pins the chain state in scratch)
         if (p == 0) L.red0[u] = v; else L.red1[u] = v;
       }
     }
@@ -749,7 +773,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r._pad = 0; r.tslot = -1; r.tidx = -1;
   r.ax = r.ay = r.rx = r.ry = 0; r.as = r.ar = r.aa = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0; r.lin_a = 0.0; r.gate_a = 1;
   bool mine = false, my_commit = false;
-  int myoff = 0, lim = 0, committed = 0, cur_n = n, nb0 = 0, nb1 = 0;
+  int myoff = 0, lim = 0, committed = 0, cur_n = n, nb0 = 0, nb1 = 0, ring_todo = 0;
+  long long ring_from = 0;
   double Tm = 0.0;
   while (stage == 0 || (done < n_steps && err == 0)) {
     bool do_eval = my_commit && r.n_stash > 2;  // stage 0: the steps that commit and change more neighbours than they could note
@@ -880,6 +905,16 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
                                  (unsigned)(ci_r | (cj_r << 8) | (ci_a << 16) | (cj_a << 24)));
       if (chg) D.nb[myoff] = make_uint2((unsigned)nb0, (unsigned)nb1);
     }
+    // temperatures of the steps that entered the window with the PREVIOUS round's commit (the ring is two rounds ahead; wave 0
+    // runs the cheapest kernels and would wait at the barrier anyway): one multiply per step, in step order, as the chain does
+    if (tid == WAVE - 1 && ring_todo > 0) {
+      double Tc = D.tring[(int)((ring_from - 1) & (long long)rmask)];
+      for (int i = 0; i < ring_todo; ++i) {
+        if (Tc > T_target) Tc *= alpha;
+        D.tring[(int)((ring_from + i) & (long long)rmask)] = Tc;
+      }
+    }
+    ring_todo = 0;
     DPH(6);
     __syncthreads();                            // (3)
     DPH(7);
@@ -1019,19 +1054,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
         props[idx] = pp;
       }
     }
-    if (tid == nthr - 1) {                      // temperatures of the steps that enter the window
-      double Tc = D.tring[(int)((done + nmax - 1) & (long long)rmask)];
-      for (int i = 0; i < committed; ++i) {
-        if (Tc > T_target) Tc *= alpha;
-        D.tring[(int)((done + nmax + i) & (long long)rmask)] = Tc;
-      }
-    }
     DPH(8);
     if (stats) { st_rounds += 1; st_eval += (unsigned long long)lim; if (any_apply) st_apply += 1; }
-    // depth of the next round: about twice what the last rounds committed
+    // depth of the next round: a multiple (gain8 / 8, default 2) of what the last rounds committed
     ema16 += committed - (ema16 >> 4);
     {
-      int want = (ema16 >> 3) + WAVES;          // 2 * mean + WAVES
+      int want = ((ema16 * gain8) >> 7) + WAVES;  // gain8 / 8 * mean + WAVES
       want = (want + WAVES - 1) / WAVES * WAVES;
       depth = want < WAVES ? WAVES : (want > nmax ? nmax : want);
     }
@@ -1042,6 +1070,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     else {
       if (any_commit && my_commit) deep_mutate(c, r, n, D.st + (size_t)5 * myoff);
       my_commit = false;
+      ring_from = done + 2 * nmax; ring_todo = committed;
       done += committed;
       n = cur_n;
     }
@@ -1051,6 +1080,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       DPH(10);
       if (my_commit) deep_mutate(c, r, n, D.st + (size_t)5 * myoff);
       my_commit = false;
+      ring_from = done + 2 * nmax; ring_todo = committed;
       done += committed;
       n = cur_n;
       stage = 1;
@@ -1086,13 +1116,13 @@ extern "C" size_t mpp_deep_static_lds_bytes(int waves) {
 template <int WAVES, bool DIAG, int OCC>
 static hipError_t launch_deep_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                                 const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
-                                int trace_tile, mpp_step_out *out, mpp_proposal *props, int nmax, int fixed_depth,
+                                int trace_tile, mpp_step_out *out, mpp_proposal *props, int nmax, int fixed_depth, int gain8,
                                 unsigned long long *stats) {
   hipError_t e = hipFuncSetAttribute((const void *)mpp_deep_kernel<WAVES, DIAG, OCC, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((mpp_deep_kernel<WAVES, DIAG, OCC, true>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0, until,
-                     trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats);
+                     trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats);
   return hipGetLastError();
 }
 
@@ -1100,11 +1130,11 @@ static hipError_t launch_deep_d(hipStream_t st, int grid, size_t lds, const DevP
 extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
-                                      mpp_proposal *props, int nmax, int fixed_depth, unsigned long long *stats) {
+                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats) {
   const bool diag = out || props;
 #define GO(W, O)                                                                                                          \
-  return diag ? launch_deep_d<W, true, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats) \
-              : launch_deep_d<W, false, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, stats)
+  return diag ? launch_deep_d<W, true, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats) \
+              : launch_deep_d<W, false, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats)
   switch (waves) {
     case 1: if (occ >= 2) { GO(1, 2); } GO(1, 1);
     case 2: if (occ >= 2) { GO(2, 2); } GO(2, 1);

@@ -130,7 +130,13 @@ def distance_merge(xy: np.ndarray, scores: np.ndarray, distance: float) -> np.nd
         # iteration order of a Python set.  The tolerance keeps the decision independent of the last-place differences
         # between scores computed on different ranks' regions.)
         sc = scores[near]
-        best = near[np.nonzero(sc >= sc.max() - 1e-9 * abs(sc.max()))[0][0]]
+        top = sc.max()
+        if np.isfinite(top):
+            best = near[np.nonzero(sc >= top - 1e-9 * abs(top))[0][0]]
+        else:
+            # a non-finite Papangelou intensity (the `craciun` contrast measure on a one-pixel mask gives inf / NaN
+            # energies): the reference's np.argmax (data_loaders.py:151) -- a NaN first, else the first infinity
+            best = near[int(np.argmax(sc))]
         removed[near] = True
         removed[best] = False
     return removed

@@ -78,8 +78,17 @@ def pack_detections(tile_ids: Sequence[int], points: Sequence[Tuple[np.ndarray, 
     return buf
 
 
+class RankFailure(RuntimeError):
+    """a rank reported a failure of its local phase in the gather (row 0, column 1 of its record buffer)"""
+
+
 def unpack_detections(gathered: np.ndarray) -> np.ndarray:
-    """[world, capacity+1, RECORD] -> [total, RECORD], ordered by (tile id, original order)."""
+    """[world, capacity+1, RECORD] -> [total, RECORD], ordered by (tile id, original order).
+    Row 0 of a rank's buffer is (count, status, 0...): a non-zero status -- the rank's sampling or packing failed -- raises
+    ``RankFailure`` on every rank alike, after the collective."""
+    failed = [r for r, g in enumerate(gathered) if g[0, 1] != 0]
+    if failed:
+        raise RankFailure(f"the local phase failed on rank(s) {failed}")
     rows = [g[1:1 + int(g[0, 0])] for g in gathered]
     allr = np.concatenate(rows, axis=0) if rows else np.zeros((0, RECORD))
     return allr[np.argsort(allr[:, 0], kind="stable")]

@@ -4,11 +4,14 @@ Mirrors the reference's ``models/mpp/mpp_model.py:43-387`` for the inference pat
 (``main.py -p infer -m mpp``): same config keys, same stored artefacts
 (``<model_path>/mpp/<name>/{config.json, calibration.json, energy_combination_model.*}``), same
 tiling / merge / scoring steps, same output files.  What changes is where the work runs: all
-tiles of an image are sampled in ONE kernel launch (one workgroup per tile) instead of a process
-pool, and with ``--gpus N`` (torchrun) tiles are dealt to ranks and the detections all-gathered.
+tiles of an image -- of many images, when a dataset is inferred -- are sampled in ONE kernel launch (one
+workgroup per tile) instead of a process pool; under ``torchrun --nproc-per-node N`` a dataset is sharded
+by image over the N GPUs (one gather of the results at the end) and a single image larger than one
+GPU's worth of chains has its tiles dealt to the ranks and the detections all-gathered.
 
-Weight learning (``train`` with ordering / integral criterion) and calibration are not part of
-this build; ``train`` supports the ``manual`` mode, which is what ``mpp_hrcM`` uses.
+``train`` covers the ``manual`` mode (what ``mpp_hrcM`` uses) and the weight learning of ``mpp_log``
+(``train_ordering_criterion.py`` / ``train_integral_criterion.py``); ``calibrate`` the three
+calibrations of ``calibration/energy_calibration.py``.
 """
 from __future__ import annotations
 
@@ -264,7 +267,8 @@ class MPPModel:
             raise ValueError("the image carries no score maps and no nets were given")
         det, marks = self.nets.infer_region(image_data.image, region)
         x0, x1, y0, y1 = region
-        return ImageWMaps(image=None, name=image_data.name, shape=(x1 - x0, y1 - y0), detection_map=det,
+        img = image_data.image[x0:x1, y0:y1] if image_data.image is not None else None     # (the classic image energies read it)
+        return ImageWMaps(image=img, name=image_data.name, shape=(x1 - x0, y1 - y0), detection_map=det,
                           param_dist_maps=marks, mappings=image_data.mappings, param_names=image_data.param_names,
                           gt_config=[], crop_data={"tl_anchor": np.array([x0, y0]), "full_shape": tuple(image_data.shape[:2])})
 
@@ -282,7 +286,8 @@ class MPPModel:
         return region
 
     @_gc_paused
-    def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1, region_data: ImageWMaps = None):
+    def infer_image(self, image_data: ImageWMaps, rank: int = 0, world_size: int = 1, region_data: ImageWMaps = None,
+                    seed: int = None):
         """Tile, sample, merge and score one image.  Returns (detections, scores): an ``EPointsSet`` for one rank,
         the list of merged ``Rectangle``s on every rank of a multi-GPU run (all ranks return the same).
 
@@ -301,7 +306,8 @@ class MPPModel:
                                                           p.get("iter_multiplier"))
         # drawn by every rank for every image, with or without tiles of its own: the generators of all ranks stay in
         # step, so the result does not depend on the number of ranks
-        seed = int(self.rng.integers(0, 2 ** 63 - 1))
+        if seed is None:
+            seed = int(self.rng.integers(0, 2 ** 63 - 1))
         if region_data is None:
             region_data = self.region_maps(image_data, rank, world_size)
         origin = region_data.crop_data["tl_anchor"] if (region_data is not None and region_data.crop_data) else np.zeros(2, int)
@@ -316,19 +322,16 @@ class MPPModel:
             import torch
             buf = torch.zeros((capacity + 1, mdist.RECORD), dtype=torch.float64, device=torch.device("cuda", self.device))
         results: List[List[Rectangle]] = [[] for _ in mine]
-        if mine:
-            sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device,
-                                       spec_waves=self.spec_waves, use_split_merge=bool(p.get("use_split_merge", False)))
-            sampler.init("naive")
-            pack = None
-            if world_size > 1:
-                def pack(ctx):
-                    ctx.pack_detections(mine, np.array([anchors[i] for i in mine]), capacity, buf)
-            out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0], on_device=pack)
-            results = [res[-1] if res else [] for res in out]
-            self.last_intensity = sampler.intensity
-            logging.info(f"ran {len(mine)} rjmcmc chains of {total} steps in one launch in "
-                         f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
+        local_error = None
+        try:
+            if mine:
+                sampler = self._sample_tiles(tiles, mine, anchors, p, total, snaps, alpha, T_target, seed, world_size, capacity, buf)
+                results = sampler.tile_results
+        except Exception as e:                      # noqa: BLE001 -- several ranks: carried through the gather, raised by all
+            if world_size == 1:
+                raise
+            local_error = e
+            sampler = None
         # what a caller may want to look at afterwards (tests compare single tiles with the CPU oracle)
         self.last_run = {"seed": seed, "anchors": anchors, "patch": patch, "mine": mine, "tile_results": results,
                          "total_steps": total, "snapshot_step": snaps[-1] if snaps else total - 1,
@@ -342,7 +345,15 @@ class MPPModel:
             return merged, scores
 
         # ---- several ranks: ONE all-gather of the device-packed records (tile id, x, y, size, ratio, angle; image coords)
-        rec = mdist.all_gather_detections(buf, device=f"cuda:{self.device}")
+        # (a rank whose local phase failed -- a chain at a hard capacity limit, a full record buffer -- says so in row 0 of its
+        # buffer; every rank then raises the same error after the collective instead of waiting for the failed one in it)
+        if local_error is not None:
+            buf.zero_()
+            buf[0, 1] = 1.0
+        try:
+            rec = mdist.all_gather_detections(buf, device=f"cuda:{self.device}")
+        except mdist.RankFailure as e:
+            raise RuntimeError(f"image {image_data.name}: {e}" + (f" (here: {local_error})" if local_error is not None else "")) from local_error
         points = [Rectangle(int(r[1]), int(r[2]), size=float(r[3]), ratio=float(r[4]), angle=float(r[5])) for r in rec]
         owned = mdist.tile_owner(n_tiles, world_size)[rec[:, 0].astype(np.int64)] == rank if len(rec) else np.zeros(0, bool)
         xy = rec[:, 1:3]
@@ -383,25 +394,44 @@ class MPPModel:
         keep = np.array(keep, dtype=np.int64)
         return [points[k] for k in keep], scores[keep]
 
+    def _sample_tiles(self, tiles, mine, anchors, p, total, snaps, alpha, T_target, seed, world_size, capacity, buf):
+        """the local phase of ``infer_image``: this rank's tiles in one launch, their configurations packed for the gather"""
+        start = time.perf_counter()
+        sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device,
+                                   spec_waves=self.spec_waves, use_split_merge=bool(p.get("use_split_merge", False)))
+        sampler.init("naive")
+        pack = None
+        if world_size > 1:
+            def pack(ctx):
+                ctx.pack_detections(mine, np.array([anchors[i] for i in mine]), capacity, buf)
+        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0], on_device=pack)
+        sampler.tile_results = [res[-1] if res else [] for res in out]
+        self.last_intensity = sampler.intensity
+        logging.info(f"ran {len(mine)} rjmcmc chains of {total} steps in one launch in "
+                     f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
+        return sampler
+
     #: tiles sampled per launch when a dataset is inferred on one GPU: tiles of consecutive images are sampled together
     #: (one workgroup per tile: a launch wants at least the 256 CUs' worth), each with the seed and chain id of its image
     TILES_PER_LAUNCH = 256
 
     @_gc_paused
-    def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None):
+    def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None, seeds: List[int] = None):
         """``infer_image`` for several images at once on one GPU: ALL their tiles in ONE launch (the reference samples
         image after image, `mpp_model.py:220-262`; a DOTA image has 4 - 40 tiles, a launch per image leaves most of the
         256 CUs idle).  Every tile keeps the seed of its image and its tile index as chain id, so each image's result is
-        exactly what ``infer_image`` returns for it, in the same order of seed draws.  Returns [(detections, scores)]."""
+        exactly what ``infer_image`` returns for it, in the same order of seed draws (``seeds``: the images' seeds when the
+        caller drew them already -- several ranks draw the seeds of ALL images of a dataset, each samples its own).
+        Returns [(detections, scores)]."""
         regions = regions or [self.region_maps(d) for d in images]
         p = self.config["inference"]["rjmcmc_params"]
         alpha, T_target, total, snaps = resolve_schedule(1, p["init_temperature"], p["alpha_t"], p["burn_in"],
                                                           p["samples_interval"], p["target_temperature"],
                                                           p.get("iter_multiplier"))
         layout, tiles, seeds, chains = [], [], [], []
-        for data, region in zip(images, regions):
+        for k, (data, region) in enumerate(zip(images, regions)):
             patch, anchors = self.tile_layout(tuple(int(v) for v in data.shape[:2]))
-            seed = int(self.rng.integers(0, 2 ** 63 - 1))
+            seed = int(self.rng.integers(0, 2 ** 63 - 1)) if seeds is None else int(seeds[k])
             mine = []
             for i, a in enumerate(anchors):
                 t = crop_image_w_maps(region, a, patch)
@@ -458,17 +488,49 @@ class MPPModel:
                 fut = pool.submit(load, patch_ids[k + 1]) if k + 1 < len(patch_ids) else None
                 yield data
 
+    #: an image is sampled by ALL ranks together (its tiles dealt to them, ``infer_image``) only when it has more tiles than
+    #: one GPU runs chains at a time; every other image of a dataset belongs to one rank (``infer``)
+    TILE_SHARD_MIN = 2048
+
+    def _result_record(self, patch_id: int, out_file: str, image_data: ImageWMaps, merged, scores) -> dict:
+        """Write ``NNNN_results.pkl`` of one image (mpp_model.py:333-366) and return what the two DOTA translators need
+        of it (plain arrays: the records of all ranks travel to rank 0 in one gather)."""
+        pts = list(merged)
+        pred_params = [sra_to_wla(p.size, p.ratio, p.angle) for p in pts]
+        pred_centers = np.array([[p.x, p.y] for p in pts]).reshape(-1, 2)
+        labels = image_data.labels
+        gt_poly = np.array([rect_to_poly(c, short=q[0], long=q[1], angle=q[2])
+                            for c, q in zip(labels["centers"], labels["parameters"])]).reshape(-1, 4, 2)
+        det_poly = np.array([rect_to_poly(c, q[0], q[1], q[2]) for c, q in zip(pred_centers, pred_params)]).reshape(-1, 4, 2)
+        difficult = np.asarray(labels.get("difficult", np.zeros(len(gt_poly), int)))
+        cats = list(labels.get("categories", ["vehicle"] * len(gt_poly)))
+        max_score = self.config["inference"].get("max_score") or 4.0
+        score01 = np.asarray(scores) / max_score
+        if len(score01) > 0 and np.max(score01) > 1.0:
+            logging.warning(f"pred score higher than max, effective score is {np.max(scores)} while param says {max_score}")
+        with open(out_file, "wb") as f:
+            pickle.dump({"detection": det_poly, "detection_points": [p.as_row() for p in pts],
+                         "detection_type": "poly", "detection_center": pred_centers,
+                         "detection_score": list(map(float, scores)), "detection_params": pred_params}, f)
+        return {"patch_id": patch_id, "gt_poly": gt_poly, "difficult": difficult, "cats": cats, "score01": score01,
+                "det_poly": det_poly}
+
     def infer(self, subset: str, min_confidence: float = 0.1, display_min_confidence: float = 0.5,
               overwrite: bool = True):
-        """Reference ``mpp_model.py:202-370`` (figures are not drawn)."""
+        """Reference ``mpp_model.py:202-370`` (figures are not drawn).
+
+        Several ranks (one per GPU): the DATASET is sharded by image -- the reference's own loop is serial over images
+        (``mpp_model.py:220``) with a process pool inside each; here rank r takes the r-th block of the images and runs them
+        through the batched one-GPU path (tiles of many images in one launch), writes their ``_results.pkl`` files, and ONE
+        gather at the end brings the DOTA lines of all ranks to rank 0.  The seeds of ALL images are drawn by every rank, so
+        every image is sampled with the seed -- and gives the files -- of a one-rank run.  Only an image with more tiles than
+        one GPU runs chains at a time (``TILE_SHARD_MIN``) is sampled by all ranks together."""
         rank, world = mdist.init_process_group()
         dataset = self.config["dataset"]["dataset"]
         results_dir = get_inference_path(os.path.split(self.save_path)[1], dataset, subset)
         os.makedirs(results_dir, exist_ok=True)
-        tr = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"])
-        tr_sv = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"], postfix="-SV")
         id_re = re.compile(r"([0-9]+).*.png")
-        todo = []
+        todo, sizes = [], []
         for pf in fetch_data_paths(dataset, subset)["images"]:
             patch_id = int(id_re.match(os.path.split(pf)[1]).group(1))
             out_file = os.path.join(results_dir, f"{patch_id:04}_results.pkl")
@@ -476,61 +538,80 @@ class MPPModel:
                 print(f"{patch_id:04}_results.pkl exists, skipping")
                 continue
             todo.append((patch_id, out_file))
+            sizes.append(pf)
+        seeds = [int(self.rng.integers(0, 2 ** 63 - 1)) for _ in todo]        # one per image, dataset order, on every rank
+        shared, own = [], list(range(len(todo)))
+        if world > 1:
+            from PIL import Image
+            n_tiles = []
+            for pf in sizes:                                                    # (the header only: no pixel is decoded)
+                with Image.open(pf) as im:
+                    n_tiles.append(len(self.tile_layout((im.size[1], im.size[0]))[1]))
+            shared = [k for k in range(len(todo)) if n_tiles[k] > self.TILE_SHARD_MIN]
+            rest = [k for k in range(len(todo)) if n_tiles[k] <= self.TILE_SHARD_MIN]
+            own = [rest[j] for j in mdist.shard_tiles(len(rest), rank, world)]
+        records, failure = [], None
+
+        # ---- images too large for one GPU: all ranks, one image at a time, tiles dealt to the ranks
+        for k, (image_data, region_data) in zip(shared, self._prefetch_images([todo[k][0] for k in shared], dataset, subset,
+                                                                                rank, world)):
+            merged, scores = self.infer_image(image_data, rank, world, region_data=region_data, seed=seeds[k])
+            if rank == 0:
+                records.append(self._result_record(todo[k][0], todo[k][1], image_data, merged, scores))
+
+        # ---- this rank's images: the tiles of consecutive images share a launch (``infer_images``)
         def inferred():
-            """(todo entry, image, detections, scores) in dataset order.  One GPU: the tiles of consecutive images share a
-            launch (``infer_images``); several ranks: image by image, each image's tiles dealt to the ranks."""
-            stream = zip(todo, self._prefetch_images([t[0] for t in todo], dataset, subset, rank, world))
-            if world > 1:
-                for entry, (image_data, region_data) in stream:
-                    merged, scores = self.infer_image(image_data, rank, world, region_data=region_data)
-                    yield entry, image_data, merged, scores
-                return
+            stream = zip(own, self._prefetch_images([todo[k][0] for k in own], dataset, subset))
             limit = int(self.config["inference"].get("tiles_per_launch", self.TILES_PER_LAUNCH))
-            batch, n_tiles, patch0 = [], 0, None
+            batch, n_batch, patch0 = [], 0, None
 
             def flush():
-                res = self.infer_images([b[1] for b in batch], [b[2] for b in batch])
-                for (entry, image_data, _), (merged, scores) in zip(batch, res):
-                    yield entry, image_data, merged, scores
+                res = self.infer_images([b[1] for b in batch], [b[2] for b in batch], seeds=[seeds[b[0]] for b in batch])
+                for (k, image_data, _), (merged, scores) in zip(batch, res):
+                    yield k, image_data, merged, scores
 
-            for entry, (image_data, region_data) in stream:
+            for k, (image_data, region_data) in stream:
                 patch, anchors = self.tile_layout(tuple(int(v) for v in image_data.shape[:2]))
-                if batch and (patch != patch0 or n_tiles + len(anchors) > limit):
+                if batch and (patch != patch0 or n_batch + len(anchors) > limit):
                     yield from flush()
-                    batch, n_tiles = [], 0
-                batch.append((entry, image_data, region_data))
-                n_tiles, patch0 = n_tiles + len(anchors), patch
+                    batch, n_batch = [], 0
+                batch.append((k, image_data, region_data))
+                n_batch, patch0 = n_batch + len(anchors), patch
             if batch:
                 yield from flush()
 
-        for (patch_id, out_file), image_data, merged, scores in inferred():
-            if rank != 0:
-                continue
-            pts = list(merged)
-            pred_params = [sra_to_wla(p.size, p.ratio, p.angle) for p in pts]
-            pred_centers = np.array([[p.x, p.y] for p in pts]).reshape(-1, 2)
-            labels = image_data.labels
-            gt_poly = np.array([rect_to_poly(c, short=q[0], long=q[1], angle=q[2])
-                                for c, q in zip(labels["centers"], labels["parameters"])]).reshape(-1, 4, 2)
-            det_poly = np.array([rect_to_poly(c, q[0], q[1], q[2]) for c, q in zip(pred_centers, pred_params)]).reshape(-1, 4, 2)
-            difficult = labels.get("difficult", np.zeros(len(gt_poly), int))
-            cats = labels.get("categories", ["vehicle"] * len(gt_poly))
-            tr.add_gt(image_id=patch_id, polygons=gt_poly, difficulty=difficult, categories=["vehicle"] * len(gt_poly))
-            tr_sv.add_gt(image_id=patch_id, polygons=gt_poly,
-                         difficulty=[bool(d) or c == "large-vehicle" for d, c in zip(difficult, cats)],
-                         categories=["vehicle"] * len(gt_poly))
-            max_score = self.config["inference"].get("max_score") or 4.0
-            score01 = np.asarray(scores) / max_score
-            if len(score01) > 0 and np.max(score01) > 1.0:
-                logging.warning(f"pred score higher than max, effective score is {np.max(scores)} while param says {max_score}")
-            for t in (tr, tr_sv):
-                t.add_detections(image_id=patch_id, scores=score01, polygons=det_poly, flip_coor=True,
-                                 class_names=["vehicle"] * len(score01))
-            with open(out_file, "wb") as f:
-                pickle.dump({"detection": det_poly, "detection_points": [p.as_row() for p in pts],
-                             "detection_type": "poly", "detection_center": pred_centers,
-                             "detection_score": list(map(float, scores)), "detection_params": pred_params}, f)
+        try:
+            for k, image_data, merged, scores in inferred():
+                records.append(self._result_record(todo[k][0], todo[k][1], image_data, merged, scores))
+        except Exception as e:                      # noqa: BLE001 -- several ranks: reported through the gather, raised by all
+            if world == 1:
+                raise
+            failure = f"rank {rank}: {type(e).__name__}: {e}"
+            logging.exception("inference failed on this rank")
+
+        # ---- ONE gather of the ranks' records (their failures included: nobody waits in a collective for a rank that raised)
+        if world > 1:
+            import torch.distributed as dist
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (records, failure))
+            failures = [f for _, f in gathered if f]
+            if failures:
+                raise RuntimeError("; ".join(failures))
+            records = [r for recs, _ in gathered for r in recs]
         if rank == 0:
+            tr = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"])
+            tr_sv = DOTAResultsTranslator(dataset, subset, results_dir, det_type="obb", all_classes=["vehicle"], postfix="-SV")
+            order = {pid: i for i, (pid, _) in enumerate(todo)}
+            for rec in sorted(records, key=lambda r: order[r["patch_id"]]):          # dataset order, as one rank writes them
+                n_gt = len(rec["gt_poly"])
+                tr.add_gt(image_id=rec["patch_id"], polygons=rec["gt_poly"], difficulty=rec["difficult"],
+                          categories=["vehicle"] * n_gt)
+                tr_sv.add_gt(image_id=rec["patch_id"], polygons=rec["gt_poly"],
+                             difficulty=[bool(d) or c == "large-vehicle" for d, c in zip(rec["difficult"], rec["cats"])],
+                             categories=["vehicle"] * n_gt)
+                for t in (tr, tr_sv):
+                    t.add_detections(image_id=rec["patch_id"], scores=rec["score01"], polygons=rec["det_poly"], flip_coor=True,
+                                     class_names=["vehicle"] * len(rec["score01"]))
             tr.save()
             tr_sv.save()
             print("saved dota translation")

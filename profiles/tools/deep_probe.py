@@ -16,6 +16,8 @@ def run(tile, objects, iters, spec, deep, fixed, reps, ntiles=1, cap=1024, repli
     ctx = hip_api.MppContext(0, point_capacity=cap, spec_waves=spec, replicas=replicas)
     ctx.set_option("deep", deep)
     ctx.set_option("deep_fixed", fixed)
+    if os.environ.get("DEEP_GAIN"):
+        ctx.set_option("deep_gain", int(os.environ["DEEP_GAIN"]))
     ctx.set_maps(np.stack([t.det for t in tiles]), [np.stack([t.marks[k] for t in tiles]) for k in range(3)])
     ctx.set_model(model, maps)
     ctx.naive_init(setup.detection_threshold, 6.0)

@@ -196,3 +196,18 @@ def test_choose_spec_waves_follows_the_measured_optimum():
     assert [choose_spec_waves(small, t) for t in (1, 256, 257, 512, 513, 1024, 1025, 2048, 4096, 16384)] == \
         [8, 8, 4, 4, 2, 2, 1, 1, 1, 1]
     assert [choose_spec_waves(small, t, use_split_merge=True) for t in (256, 512, 2048)] == [8, 8, 1]
+
+
+def test_distance_merge_tolerates_non_finite_scores():
+    """merge_patches' dedupe rule with NaN / inf Papangelou intensities (contrast setups can produce them): no
+    exception, and the reference's np.argmax choice (data_loaders.py:151)."""
+    from mpp_cnn_rs_object_detection_amd.data_loaders import distance_merge
+    xy = np.array([[10, 10], [11, 10], [10, 12], [100, 100]], dtype=float)
+    for sc, keep in (([np.nan, 1.0, 2.0, 0.5], 0), ([np.inf, 1.0, 2.0, 0.5], 0), ([1.0, np.inf, np.inf, 0.5], 1),
+                     ([1.0, 2.0, np.nan, 0.5], 2), ([-np.inf, -np.inf, -np.inf, 0.5], 0), ([1.0, 3.0, 2.0, 0.5], 1)):
+        removed = distance_merge(xy, np.array(sc), 3.0)
+        assert not removed[3]
+        assert list(np.nonzero(~removed[:3])[0]) == [keep], (sc, removed)
+    # ties within 1e-9: the first point wins
+    removed = distance_merge(xy, np.array([1.0, 1.0 + 1e-12, 1.0 - 1e-12, 0.0]), 3.0)
+    assert list(np.nonzero(~removed)[0]) == [0, 3]
