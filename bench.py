@@ -23,6 +23,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X FP32 matrix (= vector) peak, same guide; the U-Nets run in float32 like the reference's
+UNET_FLOP_PER_PIXEL = 568896.0   # PosNet 281 472 + ShapeNet 287 424 (torch.utils.flop_counter on the reference modules)
 # The roof the chain kernel actually sits under (profiles/r02b_lanes.md): issue of (mostly float64) vector instructions.
 # One SIMD issues one wave64 vector instruction per 4 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE cost"):
 N_SIMD, CLOCK_GHZ = 1024, 2.4
@@ -58,6 +60,11 @@ def main():
     ap.add_argument("--spec", type=int, default=int(os.environ.get("MPP_SPEC_WAVES", "8")))
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("MPP_SPEC_LANES", "0")),
                     help="lane mode: 4 waves x LANES lanes, one speculative step per lane (0 = one wave per step)")
+    ap.add_argument("--deep", type=int, default=int(os.environ.get("MPP_DEEP", "128")),
+                    help="deep rounds: most steps of one round (csrc/mpp_deep.hip; 0 = one wave per step, the round-2 kernel)")
+    ap.add_argument("--dataset-images", type=int, default=56,
+                    help="extra measurement, never part of `value` (0 = skip): this many 600x600 images (9 tiles each, score maps given, "
+                         "mpp_hrcM) through the batched dataset path, the images dealt to the --gpus ranks (MPPModel.infer's sharding)")
     ap.add_argument("--tiles-per-gpu", type=int, default=1)
     ap.add_argument("--cpu-baseline-chains", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,7 +106,7 @@ def main():
     maps = mappings.default_mappings()
     T = args.tiles_per_gpu
     tiles = [synth.make_tile(args.tile, args.objects, tile_id=rank * T + i) for i in range(T)]
-    ctx = hip_api.MppContext(local, point_capacity=1024, spec_waves=args.spec, spec_lanes=args.lanes)
+    ctx = hip_api.MppContext(local, point_capacity=1024, spec_waves=args.spec, spec_lanes=args.lanes, deep=args.deep)
     ctx.set_maps(np.stack([t.det for t in tiles]), [np.stack([t.marks[k] for t in tiles]) for k in range(3)])
     ctx.set_model(model, maps)
     ctx.naive_init(setup.detection_threshold, 6.0)
@@ -156,6 +163,7 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    deep_stats = ctx.deep_stats() if args.deep and args.lanes == 0 else None
     proposals = world * T * args.steps * args.iters
     value = proposals / elapsed
     kernel_ms = float(np.mean(kms))
@@ -212,21 +220,31 @@ def main():
             "gt_matched_within_2px": matched, "gt_objects": int(len(tiles[0].gt_xy)),
         },
     }
-    hbm = {
+    # the sampler is priced against HBM bandwidth with the algorithmic bytes per proposal -- that is
+    # `roofline.frac`.  The kernel does not live under that roof (the configuration is in LDS, measured traffic is below the
+    # algorithmic bytes; one chain occupies 1 of 256 CUs and is bound by the latency of its own dependency chain): what it
+    # does with the instruction issue slots of the SIMDs it occupies is reported beside it as `roofline.issue`.
+    issue = valu_roofline("one", T * args.iters / (kernel_ms * 1e-3), 4 * T) if T == 1 else None
+    roof = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "bytes per launch",
         "algorithmic_bytes_per_launch": bpp * T * args.iters, "algorithmic_bytes_per_proposal": bpp,
+        "kernel": "mpp_deep_kernel" if deep_stats else "mpp_chain_kernel", "kernel_ms": kernel_ms,
+        "issue": issue, "occupied_cu_valu_busy_frac": valu_busy,
+        "note": "one chain = one workgroup (8 waves) = 1 of 256 CUs: `frac` prices it against the whole chip's HBM roof as SURVEY "
+                "8(d) asks; `issue.frac_of_the_simds_in_use` is the share of instruction issue slots of the 4 SIMDs it runs on; "
+                "many chains: see `batched.roofline`",
     }
-    # The dominant kernel is `mpp_chain_kernel`.  Its roof is float64 vector-instruction issue, not HBM (the configuration
-    # lives in LDS; measured HBM traffic is below the algorithmic bytes): the primary block prices it against that roof,
-    # the SURVEY 8(d) HBM figure stays as `roofline.hbm`.
-    roof = valu_roofline("one", T * args.iters / (kernel_ms * 1e-3), 4 * T) if T == 1 else None
-    if roof is None:
-        roof = dict(hbm)
-    roof.update({"kernel": "mpp_chain_kernel", "kernel_ms": kernel_ms, "traffic": traffic, "hbm": hbm,
-                 "occupied_cu_valu_busy_frac": valu_busy,
-                 "note": "one chain = one workgroup (8 speculative waves) = 1 of 256 CUs; `frac` is against the whole chip, "
-                         "`frac_of_the_simds_in_use` against the 4 SIMDs it occupies; many chains: see `batched.roofline`"})
+    if deep_stats and deep_stats["rounds"]:
+        roof["deep_rounds"] = {
+            "rounds_per_launch": deep_stats["rounds"] / T, "steps_evaluated_per_committed": deep_stats["evaluated"] / max(1, deep_stats["committed"]),
+            "steps_committed_per_round": deep_stats["committed"] / deep_stats["rounds"],
+            "rounds_with_a_second_pass": deep_stats["rounds_with_change"],
+            "useful_lanes_per_wave_in_the_lane_phases": deep_stats["evaluated"] / deep_stats["rounds"] / args.spec,
+            "note": "every active lane evaluates a DIFFERENT step (no wave-uniform work repeated in 64 lanes as in the round-2 kernel): "
+                    "`useful_lanes...` of 64 lanes are active while proposals are drawn; the neighbour evaluation spreads the wave's "
+                    "(step, neighbour) pairs over all lanes",
+        }
     result["roofline"] = roof
 
     if rank == 0 and T >= 1 and not args.no_convergence:
@@ -298,6 +316,10 @@ def main():
                        "steps_per_chain": mpp.last_run["total_steps"], "region_rank0": [int(v) for v in region.shape] if region is not None else None}
                 if best is None or cur["total_s"] < best["total_s"]:
                     best = cur
+            best["nets_tflops"] = UNET_FLOP_PER_PIXEL * S * S / best["nets_s"] / 1e12 if world == 1 and best["nets_s"] > 0 else None
+            best["nets_frac_of_f32_matrix_peak"] = (best["nets_tflops"] / F32_MATRIX_PEAK_TFLOPS
+                                                    if best["nets_tflops"] and args.scene_dtype == "float32" else None)
+            best["sample_merge_score_s"] = best["total_s"] - best["nets_s"]
             result["scene"] = dict(best, image=S, rectangles_in_image=int(len(sc_xy)), nets_dtype=args.scene_dtype, ranks=world,
                                    proposals_per_s=best["tiles"] * best["steps_per_chain"] / best["total_s"],
                                    note="BASELINE config 5 end to end (max over ranks; best of 3): image recipe of data/make_synth_data.py:16-47, "
@@ -352,12 +374,62 @@ def main():
         except Exception as e:                                   # noqa: BLE001
             result["mosaic"] = {"error": f"{type(e).__name__}: {e}"}
 
+    if args.dataset_images > 0:
+        # Dataset inference (the reference's outer loop, mpp_model.py:220-262, is serial over images): the images are dealt to
+        # the ranks in blocks -- what MPPModel.infer does under torchrun -- and every rank runs its block through the batched
+        # path (tiles of many images in one launch).  Strong scaling over --gpus: the same images, more ranks.
+        try:
+            from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps
+            from mpp_cnn_rs_object_detection_amd.mpp_model import MPPModel
+            from mpp_cnn_rs_object_detection_amd.shapes import Rectangle
+            with open(os.path.join(REPO, "model_configs", "mpp", "mpp_hrcM.json")) as f:
+                cfg = json.load(f)
+            cwd = os.getcwd()
+            os.chdir(REPO)
+            try:
+                mpp = MPPModel(cfg, phase="val", load=True, device=local)
+            finally:
+                os.chdir(cwd)
+            n_img = args.dataset_images
+            mine = mdist.shard_tiles(n_img, rank, world)
+            images = []
+            for k in mine:
+                gt_xy, gt_marks = synth.make_gt(600, 260, tile_id=700 + k)
+                ddet, dmarks = synth.render_maps((600, 600), gt_xy, gt_marks)
+                images.append(ImageWMaps(name=f"{k:04}", shape=(600, 600), image=None, detection_map=ddet, param_dist_maps=dmarks,
+                                         mappings=maps, param_names=Rectangle.PARAMETERS, gt_config=[]))
+            seeds_all = [int(v) for v in np.random.default_rng(0).integers(0, 2 ** 63 - 1, size=n_img)]
+            best = None
+            for rep in range(2):
+                barrier()
+                t0 = time.perf_counter()
+                n_det = 0
+                for b in range(0, len(images), 28):                 # 28 images x 9 tiles = 252 chains per launch
+                    res = mpp.infer_images(images[b:b + 28], image_seeds=[seeds_all[k] for k in mine[b:b + 28]])
+                    n_det += sum(len(r[0]) for r in res)
+                barrier()
+                tt = torch.tensor([time.perf_counter() - t0, float(n_det)], dtype=torch.float64, device=gather_device or "cpu")
+                if world > 1:
+                    t_max = tt[:1].clone()
+                    torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+                    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
+                    tt[0] = t_max[0]
+                if best is None or float(tt[0]) < best["total_s"]:
+                    best = {"total_s": float(tt[0]), "detections": int(tt[1])}
+            result["dataset"] = dict(best, images=n_img, images_rank0=len(mine), tiles_per_image=9, steps_per_chain=30257, ranks=world,
+                                     images_per_s=n_img / best["total_s"], sharding="by image, contiguous blocks (MPPModel.infer)",
+                                     note="600x600 images with host score maps (upload, naive init, chains, merge, scores; max over ranks, "
+                                          "best of 2); with --gpus N the SAME images are dealt to N ranks (strong scaling)")
+            del mpp
+        except Exception as e:                                   # noqa: BLE001
+            result["dataset"] = {"error": f"{type(e).__name__}: {e}"}
+
     if rank == 0 and world == 1 and args.batched_tiles > 0:
         B, bt, bobj, biters = args.batched_tiles, args.batched_tile, args.batched_objects, 30257
         base = [synth.make_tile(bt, bobj, tile_id=1000 + i) for i in range(min(B, 8))]
         reps = (B + len(base) - 1) // len(base)
         B = reps * len(base)                       # 8 distinct tiles, `reps` chains (own chain id) on each of them
-        bctx = hip_api.MppContext(local, point_capacity=args.batched_capacity, spec_waves=args.batched_spec, replicas=reps)
+        bctx = hip_api.MppContext(local, point_capacity=args.batched_capacity, spec_waves=args.batched_spec, replicas=reps, deep=args.deep)
         bctx.set_maps(np.stack([t.det for t in base]), [np.stack([t.marks[k] for t in base]) for k in range(3)])
         bctx.set_model(model, maps)
         bctx.naive_init(setup.detection_threshold, 6.0)
@@ -377,9 +449,10 @@ def main():
         result["batched"] = {
             "tiles": B, "distinct_tiles": len(base), "point_capacity": args.batched_capacity, "tile": bt, "objects": bobj, "iters": biters, "spec_waves": args.batched_spec,
             "proposals_per_s": brate, "kernel_ms": kms, "wall_s": wall, "mean_final_points": float(n_end.mean()),
-            "roofline": dict(valu_roofline("many", brate, N_SIMD) or {},
-                             hbm={"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS}),
+            "roofline": {"bound": "hbm", "achieved": bbpp * brate / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": bbpp * brate / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_proposal": bbpp,
+                         "issue": valu_roofline("many", brate, N_SIMD)},
+            "deep_rounds": bctx.deep_stats() if args.deep else None,
             "note": "one workgroup per tile, all tiles in one launch; the reference's own parallel axis",
         }
         bctx.close()
@@ -409,23 +482,32 @@ def main():
                                       "the build container, BASELINE.md section 2; the reference cannot travel to the GPU box)",
         }
         # all host cores this job may use: the reference's own parallel mode is a process pool over tiles
-        # (train_utils.py:11-18); here one chain of the same tile per worker thread, each with its own oracle state
+        # (train_utils.py:11-18); here one chain of the same tile per worker thread, each with its own oracle state.  The box
+        # may show more cores than the job's CPU quota lets run at once, so the pool is timed at a few sizes up to every
+        # visible core and the BEST rate is the baseline (all of them are reported).
         try:
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(avail, int(os.environ.get("MPP_CPU_CORES", "16"))))    # a 1-GPU box grants 16 cores of the host
-        per = max(1, int(round(args.cpu_baseline_chains / 3)))
-        t1 = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=cores) as pool:
-            done_chains = sum(pool.map(cpu_chains, [range(1000 * w, 1000 * w + per) for w in range(cores)]))
-        dt = time.perf_counter() - t1
+        avail = max(1, min(avail, int(os.environ.get("MPP_CPU_CORES", str(avail)))))
+        sizes = sorted({min(avail, 16), min(avail, 64), avail})
+        sweep = []
+        for cores in sizes:
+            per = 2 if cores > 32 else 4
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                done_chains = sum(pool.map(cpu_chains, [range(1000 * w, 1000 * w + per) for w in range(cores)]))
+            dt = time.perf_counter() - t1
+            sweep.append({"threads": cores, "chains_per_thread": per, "proposals_per_s": done_chains * args.iters / dt})
+        bestc = max(sweep, key=lambda d: d["proposals_per_s"])
         result["cpu_baseline_all_cores"] = {
-            "value": done_chains * args.iters / dt, "unit": "proposals/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} threads x {per} chains x {args.iters} steps, one tile per thread (the reference's Pool-over-tiles mode, "
-                      f"train_utils.py:11-18); {avail} cores visible to the job, {os.cpu_count()} on the host",
-            "gpu_over_cpu_one_tile": value / (done_chains * args.iters / dt) if T == 1 else None,
-            "gpu_batched_over_cpu": (result.get("batched", {}).get("proposals_per_s") or 0.0) / (done_chains * args.iters / dt) or None,
+            "value": bestc["proposals_per_s"], "unit": "proposals/s", "cores": bestc["threads"], "kind": "port",
+            "sample": f"{bestc['threads']} threads x {bestc['chains_per_thread']} chains x {args.iters} steps, one tile per thread (the "
+                      f"reference's Pool-over-tiles mode, train_utils.py:11-18); {avail} cores visible to the job, {os.cpu_count()} on the host; "
+                      f"best of the pool sizes tried",
+            "pool_sizes_tried": sweep,
+            "gpu_over_cpu_one_tile": value / bestc["proposals_per_s"] if T == 1 else None,
+            "gpu_batched_over_cpu": (result.get("batched", {}).get("proposals_per_s") or 0.0) / bestc["proposals_per_s"] or None,
         }
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -360,22 +360,30 @@ class MPPModel:
         alive = np.ones(len(points), dtype=bool)
 
         def score_owned() -> np.ndarray:
-            """Papangelou intensity of this rank's alive points within the configuration of all alive points"""
-            out = np.zeros(len(points))
-            if region_data is None or not np.any(owned & alive):
-                return mdist.all_reduce_owned(out, device=f"cuda:{self.device}")
-            (h, w), (ox, oy) = region_data.shape[:2], origin
-            inside = alive & (xy[:, 0] >= ox) & (xy[:, 0] < ox + h) & (xy[:, 1] >= oy) & (xy[:, 1] < oy + w)
-            idx = np.nonzero(inside)[0]
-            local = [Rectangle(int(xy[k, 0] - ox), int(xy[k, 1] - oy), size=points[k].size, ratio=points[k].ratio,
-                               angle=points[k].angle) for k in idx]
-            unit, pair = self.energy_setup.make_energies(region_data)
-            pts = EPointsSet(local, (h, w), unit, pair, image_data=region_data, device=self.device,
-                             point_capacity=max(1024, len(local) + 64))
-            sc = pts.papangelou_all(energy_combinator=self.energy_model)
-            sel = owned[idx]
-            out[idx[sel]] = sc[sel]
-            return mdist.all_reduce_owned(out, device=f"cuda:{self.device}")
+            """Papangelou intensity of this rank's alive points within the configuration of all alive points.  The reduced
+            vector carries one more entry, the number of ranks whose local scoring failed: all ranks raise together."""
+            out = np.zeros(len(points) + 1)
+            try:
+                if region_data is not None and np.any(owned & alive):
+                    (h, w), (ox, oy) = region_data.shape[:2], origin
+                    inside = alive & (xy[:, 0] >= ox) & (xy[:, 0] < ox + h) & (xy[:, 1] >= oy) & (xy[:, 1] < oy + w)
+                    idx = np.nonzero(inside)[0]
+                    local = [Rectangle(int(xy[k, 0] - ox), int(xy[k, 1] - oy), size=points[k].size, ratio=points[k].ratio,
+                                       angle=points[k].angle) for k in idx]
+                    unit, pair = self.energy_setup.make_energies(region_data)
+                    pts = EPointsSet(local, (h, w), unit, pair, image_data=region_data, device=self.device,
+                                     point_capacity=max(1024, len(local) + 64))
+                    sc = pts.papangelou_all(energy_combinator=self.energy_model)
+                    sel = owned[idx]
+                    out[idx[sel]] = sc[sel]
+            except Exception:                       # noqa: BLE001
+                logging.exception("scoring failed on this rank")
+                out[:] = 0.0
+                out[-1] = 1.0
+            out = mdist.all_reduce_owned(out, device=f"cuda:{self.device}")
+            if out[-1] != 0:
+                raise RuntimeError(f"image {image_data.name}: scoring the gathered detections failed on {int(out[-1])} rank(s)")
+            return out[:-1]
 
         logging.info(f"merging {n_tiles} patches of {world_size} ranks ...")
         scores = score_owned()
@@ -416,11 +424,11 @@ class MPPModel:
     TILES_PER_LAUNCH = 256
 
     @_gc_paused
-    def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None, seeds: List[int] = None):
+    def infer_images(self, images: List[ImageWMaps], regions: List[ImageWMaps] = None, image_seeds: List[int] = None):
         """``infer_image`` for several images at once on one GPU: ALL their tiles in ONE launch (the reference samples
         image after image, `mpp_model.py:220-262`; a DOTA image has 4 - 40 tiles, a launch per image leaves most of the
         256 CUs idle).  Every tile keeps the seed of its image and its tile index as chain id, so each image's result is
-        exactly what ``infer_image`` returns for it, in the same order of seed draws (``seeds``: the images' seeds when the
+        exactly what ``infer_image`` returns for it, in the same order of seed draws (``image_seeds``: the images' seeds when the
         caller drew them already -- several ranks draw the seeds of ALL images of a dataset, each samples its own).
         Returns [(detections, scores)]."""
         regions = regions or [self.region_maps(d) for d in images]
@@ -431,7 +439,7 @@ class MPPModel:
         layout, tiles, seeds, chains = [], [], [], []
         for k, (data, region) in enumerate(zip(images, regions)):
             patch, anchors = self.tile_layout(tuple(int(v) for v in data.shape[:2]))
-            seed = int(self.rng.integers(0, 2 ** 63 - 1)) if seeds is None else int(seeds[k])
+            seed = int(self.rng.integers(0, 2 ** 63 - 1)) if image_seeds is None else int(image_seeds[k])
             mine = []
             for i, a in enumerate(anchors):
                 t = crop_image_w_maps(region, a, patch)
@@ -566,7 +574,7 @@ class MPPModel:
             batch, n_batch, patch0 = [], 0, None
 
             def flush():
-                res = self.infer_images([b[1] for b in batch], [b[2] for b in batch], seeds=[seeds[b[0]] for b in batch])
+                res = self.infer_images([b[1] for b in batch], [b[2] for b in batch], image_seeds=[seeds[b[0]] for b in batch])
                 for (k, image_data, _), (merged, scores) in zip(batch, res):
                     yield k, image_data, merged, scores
 
@@ -620,6 +628,8 @@ class MPPModel:
         """mpp_model.py:372-387: the "vehicle" and the small-vehicle ("-SV") DOTA files written by infer()"""
         from .dota_eval import dota_eval
         out = {}
+        if mdist.init_process_group()[0] != 0:       # several ranks: rank 0 wrote the DOTA files and evaluates them
+            return out
         for postfix in ("", "-SV"):
             out[postfix] = dota_eval(model_dir=self.save_path, dataset=self.dataset, subset="val", det_type="obb",
                                      postfix=postfix, device=self.device)

@@ -23,7 +23,7 @@ vals = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(p)):
-        if "mpp_chain" in r["Kernel_Name"]:
+        if ("mpp_chain" in r["Kernel_Name"] or "mpp_deep" in r["Kernel_Name"]):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         vals[k] = sum(v) / len(v)

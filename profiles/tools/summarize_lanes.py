@@ -21,15 +21,15 @@ for kind in ("one", "many"):
     for p in sorted(glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))):
         kt = p.replace("_counter_collection.csv", "_kernel_trace.csv")
         dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"])
-               for r in csv.DictReader(open(kt)) if "mpp_chain" in r["Kernel_Name"]}
+               for r in csv.DictReader(open(kt)) if ("mpp_chain" in r["Kernel_Name"] or "mpp_deep" in r["Kernel_Name"])}
         agg = collections.defaultdict(dict)
         for r in csv.DictReader(open(p)):
-            if "mpp_chain" in r["Kernel_Name"]:
+            if ("mpp_chain" in r["Kernel_Name"] or "mpp_deep" in r["Kernel_Name"]):
                 agg[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
         if not agg:
             continue
         # the longest PRODUCTION launch of the run (template argument DIAG = false: "<W, 0, false, ...>"), not the traced chain
-        prod = [k for k in agg if re.search(r"<\d+, \d+, false,", dur.get(k, (0, ""))[1])] or list(agg)
+        prod = [k for k in agg if re.search(r"<\d+, (\d+, )?false,", dur.get(k, (0, ""))[1])] or list(agg)
         d = max(prod, key=lambda k: dur.get(k, (0, ""))[0])
         rows = dict(agg[d], ns=dur[d][0], name=dur[d][1])
     if not rows:

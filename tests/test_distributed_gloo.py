@@ -37,6 +37,16 @@ WORKER = textwrap.dedent("""
     import torch
     rec2 = mdist.all_gather_detections(torch.from_numpy(buf))
     ok = ok and np.array_equal(rec2, expect)
+    # a rank whose local phase failed says so in row 0 of its buffer: EVERY rank raises after the collective, none waits
+    bad = buf.copy()
+    if rank == 1:
+        bad[:] = 0.0
+        bad[0, 1] = 1.0
+    try:
+        mdist.all_gather_detections(bad)
+        ok = False
+    except mdist.RankFailure as e:
+        ok = ok and "[1]" in str(e)
     print(json.dumps({"rank": rank, "world": world, "mine": mine, "ok": bool(ok), "n": int(len(rec))}))
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()

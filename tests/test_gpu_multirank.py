@@ -84,12 +84,18 @@ def run_ranks(tmp_path, world, mode, config="mpp_hrcM.json"):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), MPP_REPO=REPO, MPP_MODE=mode, MPP_CONFIG=config, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
-                                      stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=900) for p in procs]
-    for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e[-3000:]
-    return [json.loads(next(ln for ln in o.splitlines() if ln.startswith("RESULT "))[7:]) for o, _ in outs]
+        # (output goes to files: two ranks that each print tens of KB into a pipe nobody drains before the other has
+        # exited can block in print() and never reach the barrier the other waits in)
+        so, se = open(tmp_path / f"out{world}_{rank}.txt", "w"), open(tmp_path / f"err{world}_{rank}.txt", "w")
+        procs.append((subprocess.Popen([sys.executable, str(script)], env=env, stdout=so, stderr=se, text=True), so, se))
+    res = []
+    for rank, (p, so, se) in enumerate(procs):
+        rc = p.wait(timeout=900)
+        so.close(); se.close()
+        assert rc == 0, open(tmp_path / f"err{world}_{rank}.txt").read()[-3000:]
+        o = open(tmp_path / f"out{world}_{rank}.txt").read()
+        res.append(json.loads(next(ln for ln in o.splitlines() if ln.startswith("RESULT "))[7:]))
+    return res
 
 
 @pytest.mark.parametrize("config", ["mpp_hrcM.json", "config_mpp_log.json"])
@@ -125,3 +131,41 @@ def test_two_ranks_with_the_unets_sharded_by_region(tmp_path):
     assert a["region"][2] < 600 and b["region"][2] < 600 and b["region"][0] > 0
     # ... and the maps a rank computes on region + halo are those of a whole-image forward (up to conv algorithm choice)
     assert a["region_vs_full_det"] < 1e-3 and b["region_vs_full_det"] < 1e-3
+
+
+def test_two_ranks_shard_the_dataset_by_image(tmp_path):
+    """``main.py -p infer -m mpp`` on a dataset of five images with one rank and with two (gloo, both on cuda:0): the
+    reference's loop is serial over images (mpp_model.py:220-262); here rank r samples its block of the images through
+    the batched path and ONE gather brings the DOTA lines to rank 0.  Every file must be byte for byte the one-rank one."""
+    import shutil
+    from test_gpu_pipeline import write_image
+    roots = {}
+    for world in (1, 2):
+        root = tmp_path / f"w{world}"
+        os.makedirs(root)
+        for d in ("model_configs", "models_storage"):
+            shutil.copytree(os.path.join(REPO, d), root / d)
+        with open(root / "paths_config.json", "w") as f:
+            json.dump({"dataset_path": ["data/"], "model_path": ["models_storage/"]}, f)
+        for k in range(5):
+            write_image(root, "val", 3 + 2 * k, 60 + k)
+        port = free_port()
+        procs = []
+        for rank in range(world):
+            env = dict(os.environ, PYTHONPATH=REPO, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), MPP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            se = open(root / f"err{rank}.txt", "w")
+            procs.append((subprocess.Popen([sys.executable, os.path.join(REPO, "main.py"), "-p", "infer", "-m", "mpp", "-c", "mpp_hrcM",
+                                            "-d", "SYNTH", "-o"], cwd=root, env=env, stdout=subprocess.DEVNULL, stderr=se, text=True), se))
+        for rank, (p, se) in enumerate(procs):
+            rc = p.wait(timeout=900)
+            se.close()
+            assert rc == 0, open(root / f"err{rank}.txt").read()[-3000:]
+        roots[world] = root / "data" / "inference" / "SYNTH" / "val" / "mpp_hrcM"
+    files = sorted(os.path.relpath(os.path.join(d, f), roots[1]) for d, _, fs in os.walk(roots[1]) for f in fs)
+    assert len([f for f in files if f.endswith("_results.pkl")]) == 5 and any(f.endswith("vehicle.txt") for f in files)
+    for f in files:
+        assert open(roots[1] / f, "rb").read() == open(roots[2] / f, "rb").read(), f"{f} differs between one and two ranks"
+    # the two ranks really split the work: 2 + 3 images
+    log = [open(tmp_path / "w2" / f"err{r}.txt").read() for r in range(2)]
+    assert "(2 images)" in log[0] and "(3 images)" in log[1]
