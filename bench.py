@@ -404,9 +404,24 @@ def main():
                 barrier()
                 t0 = time.perf_counter()
                 n_det = 0
-                for b in range(0, len(images), 28):                 # 28 images x 9 tiles = 252 chains per launch
-                    res = mpp.infer_images(images[b:b + 28], image_seeds=[seeds_all[k] for k in mine[b:b + 28]])
-                    n_det += sum(len(r[0]) for r in res)
+                # 28 images x 9 tiles = 252 chains per launch; as in MPPModel.infer a worker thread brings the next batch's score
+                # maps to the GPU (side stream) while this batch's chains run
+                from concurrent.futures import ThreadPoolExecutor
+                side = torch.cuda.Stream(device=device)
+
+                def upload(b):
+                    with torch.cuda.stream(side):
+                        r = mpp._regions_of_batch(images[b:b + 28])
+                    side.synchronize()
+                    return r
+
+                with ThreadPoolExecutor(max_workers=1) as pool:
+                    fut = pool.submit(upload, 0) if images else None
+                    for b in range(0, len(images), 28):
+                        regions = fut.result()
+                        fut = pool.submit(upload, b + 28) if b + 28 < len(images) else None
+                        res = mpp.infer_images(images[b:b + 28], regions, image_seeds=[seeds_all[k] for k in mine[b:b + 28]])
+                        n_det += sum(len(r[0]) for r in res)
                 barrier()
                 tt = torch.tensor([time.perf_counter() - t0, float(n_det)], dtype=torch.float64, device=gather_device or "cpu")
                 if world > 1:

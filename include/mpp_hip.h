@@ -196,6 +196,17 @@ int mpp_delta_vectors(mpp_ctx *ctx, int tile, int n_cases, const int32_t *rem_of
                       double *before, double *after, unsigned char *mask);
 /* papangelou(u, remove_u_from_point_set=True, return_energy_delta=True) of every point */
 int mpp_papangelou(mpp_ctx *ctx, int tile, double *dE);
+/* merge_patches(..., method='distance', distance) of models/mpp/data_loaders.py:122-161 and the two scorings around it
+ * (mpp_model.py:296-304), for EVERY tile of the ctx at once: a tile holds the aggregated detections of one image (mpp_set_points)
+ * on that image's score maps.  On the device: the Papangelou intensity of every point in its tile's configuration; the walk
+ * of data_loaders.py:140-159 -- in index order every not-yet-removed point keeps, among the not-yet-removed points within
+ * `distance` of it, only the one with the best intensity (scores equal to 1e-9 tie, the first wins) --; the removals in the
+ * order EPointsSet.remove leaves (the last point takes the hole); the Papangelou values of the survivors.  The tiles'
+ * configurations ARE the survivors afterwards.  n_out [n_tiles], xy [n_tiles][cap][2], marks [n_tiles][cap][3], dE
+ * [n_tiles][cap] = E(with u) - E(without u) (score = exp(-dE)), n_removed [n_tiles] (may be NULL).  -4: a tile holds more
+ * points than the device walk takes (8192): merge that image on the host. */
+int mpp_merge_score(mpp_ctx *ctx, double distance, int cap, int32_t *n_out, int32_t *xy, double *marks, double *dE,
+                    int32_t *n_removed);
 /* naive_detection (sample_rjmcmc.py:23-35): threshold + greedy distance-NMS, sets every tile's points */
 int mpp_naive_init(mpp_ctx *ctx, double threshold, double nms_distance);
 

@@ -22,6 +22,11 @@ extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int gr
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
                                       mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats);
+extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
+                                            double *dE);
+extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int cap, const double *dE, int dist2,
+                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
+                                        int32_t *n_removed);
 extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -161,7 +166,7 @@ static const char *chain_error_text(int e) {
 }
 
 // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections; 5: mpp_set_chain_keys, options auto_grow / remap_table
-extern "C" int mpp_abi_version(void) { return 6; }
+extern "C" int mpp_abi_version(void) { return 7; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -800,6 +805,58 @@ extern "C" int mpp_papangelou(mpp_ctx *c, int tile, double *dE) {
   if (rc) return rc;
   for (int i = 0; i < n; ++i) dE[i] = -dE[i];     // E(with u) - E(without u), energy_point_set.py:108-110
   return 0;
+}
+
+// merge_patches(method='distance') for every tile of the ctx at once (data_loaders.py:122-161): each tile holds the
+// aggregated detections of one image on that image's score maps.  Papangelou of every point, the dedupe walk, the
+// removals (EPointsSet.remove order), Papangelou of the survivors -- four launches for the whole batch, one copy back.
+#define MPP_MERGE_MAX_POINTS 8192
+extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_out, int32_t *xy, double *marks, double *dE,
+                               int32_t *n_removed) {
+  if (!c || !n_out || cap < 0 || !(distance >= 0)) return fail(c, -1, "bad merge_score arguments");
+  if (!c->have_maps || !c->have_model) return fail(c, -1, "mpp_set_maps / mpp_set_model have not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = push_state(c);
+  if (rc) return rc;
+  const int T = c->n_tiles;
+  std::vector<int32_t> n0(T);
+  HIPCHK(c, hipMemcpyAsync(n0.data(), c->n, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int max_n = 0;
+  for (int t = 0; t < T; ++t) max_n = n0[t] > max_n ? n0[t] : max_n;
+  if (max_n > MPP_MERGE_MAX_POINTS || c->cap > 65536)
+    return fail(c, -4, "merge_score: a tile holds %d points (the device walk takes at most %d): merge it on the host", max_n,
+                MPP_MERGE_MAX_POINTS);
+  const size_t TC = (size_t)T * c->cap;
+  double *d_dE = nullptr, *ts = nullptr, *tr = nullptr, *ta = nullptr;
+  int32_t *work = nullptr, *slot_of = nullptr, *tx = nullptr, *ty = nullptr, *d_rem = nullptr;
+  hipError_t e = hipSuccess;
+  auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
+  A((void **)&d_dE, TC * 8); A((void **)&ts, TC * 8); A((void **)&tr, TC * 8); A((void **)&ta, TC * 8);
+  A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
+  std::vector<int32_t> h_rem(T, 0);
+  if (e == hipSuccess && max_n > 0) {
+    const int dist2 = (int)floor(distance * distance + 1e-9);
+    mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
+    mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, c->cap, d_dE, dist2, work, slot_of, tx, ty, ts, tr, ta, d_rem);
+    mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  }
+  if (e == hipSuccess) rc = mpp_get_points_all(c, cap, n_out, xy, marks);
+  if (e == hipSuccess && rc == 0 && dE && cap > 0 && max_n > 0) {
+    const int m = max_n < cap ? max_n : cap;
+    std::vector<double> h((size_t)T * m);
+    e = hipMemcpy2D(h.data(), (size_t)m * 8, d_dE, (size_t)c->cap * 8, (size_t)m * 8, T, hipMemcpyDeviceToHost);
+    for (int t = 0; t < T && e == hipSuccess; ++t)
+      for (int i = 0; i < n_out[t] && i < m; ++i) dE[(size_t)t * cap + i] = h[(size_t)t * m + i];
+  }
+  if (n_removed) for (int t = 0; t < T; ++t) n_removed[t] = h_rem[t];
+  void *fr[] = {d_dE, ts, tr, ta, slot_of, tx, ty, d_rem};
+  for (void *p : fr) if (p) (void)hipFree(p);
+  HIPCHK(c, e);
+  return rc;
 }
 
 extern "C" int mpp_naive_init(mpp_ctx *c, double threshold, double nms_distance) {

@@ -204,6 +204,158 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
   if (threadIdx.x == 0) dE[cs] = part[0];
 }
 
+// ---- merge_patches(method='distance') on the device, for every tile of a ctx at once ------------------------------------
+// (data_loaders.py:122-161: the aggregated detections of an image are scored -- Papangelou intensity of each point in the
+// full configuration --, points closer than `distance` keep only the best of them, the survivors are scored again.  One
+// "tile" of the ctx = one image's aggregated configuration on the image's score maps; a dataset batch = many tiles.)
+
+// Papangelou of every point: dE[tile][i] = E(with u_i) - E(without u_i), i.e. minus the delta of removing it.  One wave per
+// point, the body of k_delta_batch with the one removal (same lanes, same reduction tree: the values of mpp_papangelou).
+__global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, const TileRef *tiles, int cap, double *dE) {
+  __shared__ double part[64];
+  __shared__ int32_t ex;
+  const int tile = blockIdx.y, cs = blockIdx.x;
+  TileRef t = tiles[tile];
+  const int n = *t.n;
+  if (cs >= n) return;
+  if (threadIdx.x == 0) ex = cs;
+  __syncthreads();
+  Overlay o{1, &ex, 0, nullptr, nullptr};
+  Overlay none{0, nullptr, 0, nullptr, nullptr};
+  const Grid g{nullptr, nullptr};
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    Rect u = tile_rect(t, i);
+    if (i == cs) { acc -= point_energy(P, t, n, u, i, -1, none, nullptr, g); continue; }
+    double dx = (double)(u.x - t.px[cs]), dy = (double)(u.y - t.py[cs]);
+    if (sqrt(dx * dx + dy * dy) <= P->max_inter)
+      acc += point_energy(P, t, n, u, i, -1, o, nullptr, g) - point_energy(P, t, n, u, i, -1, none, nullptr, g);
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = (int)blockDim.x / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dE[(size_t)tile * cap + cs] = -part[0];
+}
+
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const double w = __shfl_xor(v, o, WAVE); v = w > v ? w : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
+  return v;
+}
+// The dedupe walk of distance_merge (data_loaders.py:140-159 as restated in this repo's data_loaders.distance_merge): in
+// index order, every not-yet-removed point keeps, among the not-yet-removed points within `distance` of it (itself
+// included), only the one with the best intensity exp(-dE) -- scores equal to 1e-9 are a tie and the first wins; a
+// non-finite best score: numpy's argmax (a NaN first, else the first infinity).  Then the removals in index order, each
+// moving the last point into the hole (EPointsSet.remove), which fixes the order of the survivors.  One wave per tile.
+// work: [T][cap] (alive flag, then the survivors' original indices); tmp*: [T][cap] copies of the configuration.
+__global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int cap, const double *dE, int dist2, int32_t *work,
+                                                     int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
+                                                     int32_t *n_removed) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  TileRef t = tiles[tile];
+  const int n = *t.n;
+  extern __shared__ unsigned char alive[];                     // [cap] flags (LDS: read in every inner loop)
+  int32_t *sl = slot_of + (size_t)tile * cap;
+  const double *d = dE + (size_t)tile * cap;
+  (void)work;
+  for (int j = lane; j < n; j += WAVE) alive[j] = 1;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int i = 0; i < n; ++i) {
+    if (!alive[i]) continue;                                   // (uniform: every lane reads the same flag)
+    const int xi = t.px[i], yi = t.py[i];
+    // best score among the alive points within the distance (i itself is one of them)
+    double top = -INFINITY;
+    int first_nan = 0x7fffffff, cnt = 0;
+    for (int j = lane; j < n; j += WAVE) {
+      const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+      if (alive[j] && dx * dx + dy * dy <= dist2) {
+        const double sc = exp(-d[j]);
+        ++cnt;
+        if (sc != sc) first_nan = j < first_nan ? j : first_nan;
+        else top = sc > top ? sc : top;
+      }
+    }
+    cnt = wave_sum_i(cnt);
+    if (cnt <= 1) continue;                                    // alone: its own best, nothing to remove
+    top = wave_max_d(top);
+    first_nan = wave_min_i(first_nan);
+    const bool finite = first_nan == 0x7fffffff && top - top == 0.0;
+    const double thr = finite ? top - 1e-9 * fabs(top) : top;
+    int best = 0x7fffffff;
+    if (first_nan != 0x7fffffff) best = first_nan;             // numpy.argmax: the first NaN
+    else {
+      for (int j = lane; j < n; j += WAVE) {
+        const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+        if (alive[j] && dx * dx + dy * dy <= dist2) {
+          const double sc = exp(-d[j]);
+          if (finite ? sc >= thr : sc == top) best = j < best ? j : best;
+        }
+      }
+      best = wave_min_i(best);
+    }
+    for (int j = lane; j < n; j += WAVE) {
+      const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+      if (j != best && alive[j] && dx * dx + dy * dy <= dist2) alive[j] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  // the survivors' order: removals in index order, the last point takes the hole
+  int32_t *orig_at = tx + (size_t)tile * cap;                  // (reused below: first the permutation, then the copy)
+  for (int j = lane; j < n; j += WAVE) {
+    sl[j] = j;
+    ts[(size_t)tile * cap + j] = t.ps[j]; tr[(size_t)tile * cap + j] = t.pr[j]; ta[(size_t)tile * cap + j] = t.pa[j];
+    ty[(size_t)tile * cap + j] = (t.px[j] & 0xffff) | (t.py[j] << 16);
+    orig_at[j] = j;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  int m = n;
+  if (lane == 0) {
+    for (int k = 0; k < n; ++k)
+      if (!alive[k]) {
+        const int slot = sl[k], last = orig_at[m - 1];
+        --m;
+        if (last != k) { orig_at[slot] = last; sl[last] = slot; }
+      }
+    *t.n = m;
+    n_removed[tile] = n - m;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  m = __shfl(m, 0, WAVE);
+  for (int j = lane; j < m; j += WAVE) {
+    const int o = orig_at[j];
+    const int xy = ty[(size_t)tile * cap + o];
+    t.px[j] = xy & 0xffff; t.py[j] = (xy >> 16) & 0xffff;
+    t.ps[j] = ts[(size_t)tile * cap + o]; t.pr[j] = tr[(size_t)tile * cap + o]; t.pa[j] = ta[(size_t)tile * cap + o];
+  }
+}
+extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
+                                            double *dE) {
+  if (n_tiles <= 0 || max_n <= 0) return;
+  hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE);
+}
+extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int cap, const double *dE, int dist2,
+                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
+                                        int32_t *n_removed) {
+  if (n_tiles <= 0) return;
+  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), (size_t)cap, st, tiles, cap, dE, dist2, work, slot_of, tx, ty, ts, tr, ta, n_removed);
+}
+
 // The same walk, but the per-point energy VECTORS (unit terms, then pair reductions) before and after the
 // perturbation are written out instead of being combined: the weight-learning criterion differentiates the
 // combinator on them (train_ordering_criterion.py:101-118 with EnergyComputeTorch, :27-40).

@@ -21,6 +21,7 @@ from . import mappings as _mappings
 from .custom_types import ImageWMaps
 from .paths import fetch_data_paths, get_dataset_base_path, get_inference_path
 from .point_set import EPointsSet
+from .energies import build_model_desc as E_build
 from .shapes import Rectangle, wla_to_sra
 
 PARAM_NAMES = ["size", "ratio", "angle"]
@@ -169,6 +170,68 @@ def merge_patches(patches: List[ImageWMaps], results: List[List[Rectangle]], ori
         for i in np.nonzero(removed)[0]:
             agg.remove(merged[i])
     return agg
+
+
+class Detections:
+    """The merged detections of an image as arrays -- ``xy`` [n, 2] int, ``marks`` [n, 3] (size, ratio, angle) -- that
+    reads like the list of ``Rectangle`` the reference's ``merge_patches`` hands on (iteration, ``len``, indexing build the
+    objects on demand): objects only at the API edge."""
+
+    def __init__(self, xy: np.ndarray, marks: np.ndarray):
+        self.xy = np.asarray(xy, dtype=np.int64).reshape(-1, 2)
+        self.marks = np.asarray(marks, dtype=np.float64).reshape(-1, 3)
+        self._objs = None
+
+    def _list(self) -> List[Rectangle]:
+        if self._objs is None:
+            self._objs = [Rectangle(x, y, size=s, ratio=r, angle=a)
+                          for (x, y), (s, r, a) in zip(self.xy.tolist(), self.marks.tolist())]
+        return self._objs
+
+    def __len__(self):
+        return len(self.xy)
+
+    def __iter__(self):
+        return iter(self._list())
+
+    def __getitem__(self, i):
+        return self._list()[i]
+
+
+def merge_score_images(regions: List[ImageWMaps], aggregated, energy_model, energy_setup, distance: float, device: int = 0):
+    """``merge_patches(method='distance')`` + the final Papangelou scores (mpp_model.py:296-304) for SEVERAL images of one
+    shape in four kernel launches (``mpp_merge_score``): ``aggregated[k]`` = (xy, marks) of image k's detections in image
+    coordinates, tile order; ``regions[k]`` its score maps (device tensors, or arrays).  -> [(Detections, scores)].
+    The survivors, their order and their scores are those of ``merge_patches`` followed by ``papangelou_all``."""
+    import torch
+    from .hip_api import MppContext
+    dev = torch.device("cuda", device)
+
+    def stack(arrs):
+        if all(hasattr(a, "data_ptr") for a in arrs):
+            base = arrs[0]._base if hasattr(arrs[0], "_base") else None
+            # (views of one batch tensor, in order: borrow it as it is instead of copying 100 B per pixel)
+            if base is not None and len(base) == len(arrs) and all(a._base is base and a.data_ptr() == base[k].data_ptr()
+                                                                   for k, a in enumerate(arrs)) and base.is_contiguous():
+                return base
+            return torch.stack(list(arrs)).contiguous()
+        return torch.from_numpy(np.stack([np.asarray(a, dtype=np.float32) for a in arrs])).to(dev)
+
+    det = stack([r.detection_map for r in regions])
+    marks = [stack([r.param_dist_maps[k] for r in regions]) for k in range(3)]
+    unit, pair = energy_setup.make_energies(regions[0])
+    n_max = max((len(a[0]) for a in aggregated), default=0)
+    ctx = MppContext(device, point_capacity=max(256, n_max + 64))
+    try:
+        ctx.set_maps(det, marks)
+        ctx.set_model(E_build(unit, pair, energy_model), regions[0].mappings)
+        for k, (xy, mk) in enumerate(aggregated):
+            ctx.set_points(k, np.asarray(xy, dtype=np.int32).reshape(-1, 2), np.asarray(mk, dtype=np.float64).reshape(-1, 3))
+        res, removed = ctx.merge_score(distance)
+    finally:
+        ctx.close()
+    logging.info(f"merge removing {removed.tolist()} point(s) of {len(regions)} image(s)")
+    return [(Detections(xy, mk), np.exp(-dE)) for xy, mk, dE in res]
 
 
 def crop_region(image_data: ImageWMaps, region) -> ImageWMaps:

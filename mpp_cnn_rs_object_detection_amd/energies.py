@@ -42,6 +42,9 @@ class UnitTerm:
     params: Sequence[float] = ()
     #: the prepared picture a classic image energy reads ([H, W, C] float32; ``contrast_term`` / ``gradient_term``)
     image: Optional[np.ndarray] = None
+    #: ``ContrastEnergy.q_fun`` (classics.py:109,162-163): a Python callable applied to the value.  A chain cannot call back
+    #: into Python: ``classic_values`` applies it, ``build_model_desc`` refuses a term that carries one
+    q_fun: Optional[object] = None
 
 
 @dataclass
@@ -166,6 +169,10 @@ def build_model_desc(unit_terms: Sequence[UnitTerm], pair_terms: Sequence[PairTe
     if len(unit_terms) > MAX_UNIT or len(pair_terms) > MAX_PAIR:
         raise ValueError(f"at most {MAX_UNIT} unit and {MAX_PAIR} pair terms")
     names = [t.name for t in unit_terms] + [t.name for t in pair_terms]
+    for t in unit_terms:
+        if getattr(t, "q_fun", None) is not None and not getattr(t, "_q_fun_on_host", False):
+            raise ValueError(f"{t.name}: q_fun is a Python callable -- available through classic_values() only, not inside a chain "
+                             "(no shipped energy setup sets it, energy_setup_contrast.py:29-205)")
     if len(set(names)) != len(names):
         raise AssertionError(f"duplicate energy names in {names}")      # energy_graph.py:37-42
     if combinator is None:
@@ -268,7 +275,7 @@ CONTRAST_MEASURES = {"lafarge": (0, 1.0, 1e1), "craciun": (1, -1.0, 0.0), "craci
 
 
 def contrast_term(name: str, image, dilation: int, contrast_measure_type: str, gap: int = 0, rgb: bool = False,
-                  thresh: float = 0.0, erode: int = 0, normalize: bool = False) -> UnitTerm:
+                  thresh: float = 0.0, erode: int = 0, normalize: bool = False, q_fun=None) -> UnitTerm:
     """``ContrastEnergy(...)`` (classics.py:100-149) as a term of the flat model: the measure's index, sign and default
     value, and the picture ``compute`` reads -- the channel mean for ``rgb=False`` (taken BEFORE any normalisation, as the
     reference does), the (optionally normalised) picture itself for ``rgb=True``."""
@@ -284,7 +291,7 @@ def contrast_term(name: str, image, dilation: int, contrast_measure_type: str, g
             pic = pic - np.mean(pic, axis=(0, 1))
             pic = pic / np.mean(np.abs(pic), axis=(0, 1))
     return UnitTerm(name, U_CONTRAST, [idx, int(dilation), int(gap), int(erode), float(thresh), fac, default],
-                    image=np.ascontiguousarray(pic, dtype=np.float32))
+                    image=np.ascontiguousarray(pic, dtype=np.float32), q_fun=q_fun)
 
 
 def gradient_term(name: str, image, dilation: int = 1, eps: float = 1e-8, thresh: float = 0.0,
@@ -320,11 +327,18 @@ def classic_values(term: UnitTerm, rects, mappings=None, device: int = 0) -> np.
     ctx = MppContext(device, point_capacity=max(256, len(rects)))
     ctx.set_maps(np.zeros((H, W), np.float32), [np.zeros((H, W, 32), np.float32)] * 3)
     ctx.set_image(term.image)
-    ctx.set_model(build_model_desc([term], [], None), mappings or default_mappings())
+    plain = UnitTerm(term.name, term.kind, term.params, image=term.image)        # the value before q_fun
+    ctx.set_model(build_model_desc([plain], [], None), mappings or default_mappings())
     ctx.set_points(0, np.array([[u.x, u.y] for u in rects], np.int32),
                    np.array([[u.size, u.ratio, u.angle] for u in rects], np.float64))
     _, vec = ctx.total_energy(0, return_vectors=True)
-    return np.asarray(vec)[:, 0].copy()
+    vals = np.asarray(vec)[:, 0].copy()
+    if term.q_fun is not None:
+        # classics.py:154-163: q_fun is applied to the measured value only -- a rectangle without fill pixels returns the
+        # measure's default value as it is
+        default = float(term.params[6]) if term.kind == U_CONTRAST else None
+        vals = np.array([v if (default is not None and v == default) else term.q_fun(v) for v in vals], dtype=np.float64)
+    return vals
 
 
 class ContrastMeasureEnergySetup(EnergySetup):

@@ -24,7 +24,7 @@ MAX_UNIT, MAX_PAIR, NCLASS, NKERNEL = 8, 2, 32, 10
 ABI_SYMBOLS = [
     "mpp_create", "mpp_destroy", "mpp_last_error", "mpp_set_stream", "mpp_synchronize", "mpp_set_option",
     "mpp_get_option", "mpp_set_maps", "mpp_set_image", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
-    "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_naive_init", "mpp_set_schedule",
+    "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_merge_score", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
     "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
@@ -116,6 +116,7 @@ def load_library(path: Optional[str] = None):
         "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
         "mpp_papangelou": (i32, [vp, i32, vp]),
+        "mpp_merge_score": (i32, [vp, C.c_double, i32, vp, vp, vp, vp, vp]),
         "mpp_naive_init": (i32, [vp, dbl, dbl]),
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
         "mpp_replay": (i32, [vp, i32, i32, vp, vp]),
@@ -417,6 +418,17 @@ class MppContext:
         return out[:self.count(tile)]
 
     # -- the chain -----------------------------------------------------------------------------
+    def merge_score(self, distance: float):
+        """``merge_patches(method='distance')`` and the two scorings around it for every tile of the ctx on the device
+        (``mpp_merge_score``): -> [(xy, marks, dE)] of the survivors per tile (score = exp(-dE)), and the removed counts."""
+        T = self.get_option("n_chains")
+        cap = int(max(1, self.counts()[:T].max(initial=0)))
+        n = np.zeros(T, np.int32)
+        xy, marks = np.zeros((T, cap, 2), np.int32), np.zeros((T, cap, 3), np.float64)
+        dE, removed = np.zeros((T, cap), np.float64), np.zeros(T, np.int32)
+        self._check(self._L.mpp_merge_score(self._h, float(distance), cap, _ptr(n), _ptr(xy), _ptr(marks), _ptr(dE), _ptr(removed)))
+        return [(xy[t, :n[t]].copy(), marks[t, :n[t]].copy(), dE[t, :n[t]].copy()) for t in range(T)], removed
+
     def replay(self, tile: int, tape: np.ndarray) -> np.ndarray:
         tape = np.ascontiguousarray(tape, dtype=PROPOSAL_DTYPE)
         out = np.zeros(len(tape), STEPOUT_DTYPE)

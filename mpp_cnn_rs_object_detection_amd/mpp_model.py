@@ -31,7 +31,8 @@ from . import distributed as mdist
 from . import energies as E
 from .custom_types import ImageWMaps
 from .data_loaders import (PATCH_SIZE, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps, merge_patches,
-                           tile_anchors)
+                           merge_score_images, tile_anchors)
+from .hip_api import MppError
 from .point_set import EPointsSet
 from .dota_results import DOTAResultsTranslator
 from .paths import fetch_data_paths, get_inference_path, get_model_base_path
@@ -431,7 +432,7 @@ class MPPModel:
         exactly what ``infer_image`` returns for it, in the same order of seed draws (``image_seeds``: the images' seeds when the
         caller drew them already -- several ranks draw the seeds of ALL images of a dataset, each samples its own).
         Returns [(detections, scores)]."""
-        regions = regions or [self.region_maps(d) for d in images]
+        regions = regions or self._regions_of_batch(images)
         p = self.config["inference"]["rjmcmc_params"]
         alpha, T_target, total, snaps = resolve_schedule(1, p["init_temperature"], p["alpha_t"], p["burn_in"],
                                                           p["samples_interval"], p["target_temperature"],
@@ -455,9 +456,27 @@ class MPPModel:
         sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device, spec_waves=self.spec_waves,
                                    use_split_merge=bool(p.get("use_split_merge", False)), keys=(seeds, chains))
         sampler.init("naive")
-        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed=0, chain0=0)
+        # merge + scores on the device for the whole batch when the images share a shape and a picture-free energy setup
+        # (the classic image energies read a per-image picture the batch context does not hold)
+        on_device = (len({tuple(int(v) for v in r.shape[:2]) for r in regions}) == 1 and E.classic_image(sampler.model_units) is None
+                     and not self.config["inference"].get("host_merge", False))
+        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed=0, chain0=0, as_arrays=on_device)
         logging.info(f"ran {len(tiles)} rjmcmc chains ({len(images)} images) of {total} steps in one launch in "
                      f"{time.perf_counter() - start:.2f}s (kernel {sampler.kernel_ms:.1f} ms)")
+        if on_device:
+            aggregated = []
+            for first, n in layout:
+                xy = [out[t][-1][0] + np.asarray(tiles[t].crop_data["tl_anchor"], dtype=np.int32) for t in range(first, first + n)]
+                mk = [out[t][-1][1] for t in range(first, first + n)]
+                aggregated.append((np.concatenate(xy) if xy else np.zeros((0, 2), np.int32),
+                                   np.concatenate(mk) if mk else np.zeros((0, 3))))
+            try:
+                return merge_score_images(regions, aggregated, self.energy_model, self.energy_setup, 3, device=self.device)
+            except MppError as e:
+                if e.code != -4:                      # (-4: an image with more points than the device walk takes)
+                    raise
+                from .sampler import _to_rectangles
+                out = [[_to_rectangles(*o[-1])] for o in out]
         results = []
         for (first, n), data, region in zip(layout, images, regions):
             res = [r[-1] if r else [] for r in out[first:first + n]]
@@ -467,6 +486,27 @@ class MPPModel:
             scores = merged.papangelou_all(energy_combinator=self.energy_model) if len(merged) else np.zeros(0)
             results.append((merged, scores))
         return results
+
+    def _regions_of_batch(self, images: List[ImageWMaps]) -> List[ImageWMaps]:
+        """Score maps of a batch of images on the GPU.  Host maps of one shape go into ONE tensor per map kind (the images
+        are views of it): the batch's merge / scoring context borrows those tensors as they are."""
+        if (self.nets is not None or any(d.detection_map is None or hasattr(d.detection_map, "data_ptr") for d in images)
+                or len({tuple(np.shape(d.detection_map)) for d in images}) != 1):
+            return [self.region_maps(d) for d in images]
+        import torch
+        dev = torch.device("cuda", self.device)
+        B, (H, W) = len(images), np.shape(images[0].detection_map)
+        det = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        marks = [torch.empty((B, H, W) + tuple(np.shape(images[0].param_dist_maps[k])[2:]), dtype=torch.float32, device=dev) for k in range(3)]
+        regions = []
+        for i, d in enumerate(images):
+            det[i].copy_(torch.from_numpy(np.ascontiguousarray(d.detection_map, dtype=np.float32)))
+            for k in range(3):
+                marks[k][i].copy_(torch.from_numpy(np.ascontiguousarray(d.param_dist_maps[k], dtype=np.float32)))
+            r = crop_region(d, (0, H, 0, W))
+            r.detection_map, r.param_dist_maps = det[i], [marks[k][i] for k in range(3)]
+            regions.append(r)
+        return regions
 
     def _prefetch_images(self, patch_ids, dataset, subset, rank: int = 0, world_size: int = 1):
         """Images with the score maps of this rank's region, one image ahead of the consumer: while the chain kernel of

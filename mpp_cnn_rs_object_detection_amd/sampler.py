@@ -95,6 +95,7 @@ class TileBatchSampler:
         self.energy_combinator = energy_combinator
         self.mappings = tiles[0].mappings
         unit, pair = energy_setup.make_energies(tiles[0])
+        self.model_units = unit
         self.model = E.build_model_desc(unit, pair, energy_combinator)
         auto_spec = spec_waves is None
         self.ctx = ctx or MppContext(device, point_capacity=point_capacity, spec_waves=8 if auto_spec else spec_waves)
@@ -141,10 +142,11 @@ class TileBatchSampler:
         self.ctx.set_kernels(make_kernels(self.mappings, 1.0, use_split_merge=self.use_split_merge), intensity=self.intensity)
 
     def run(self, total_steps: int, snapshot_steps: Sequence[int], num_samples: int, T0: float, alpha: float,
-            T_target: float, seed: int, chain0: int = 0, on_device=None):
+            T_target: float, seed: int, chain0: int = 0, on_device=None, as_arrays: bool = False):
         """-> per tile, the list of the last ``num_samples`` sampled configurations.
         ``on_device``: a callable ``f(ctx)`` that takes each sampled state where it lies (e.g.
-        ``ctx.pack_detections`` into an all-gather buffer) instead of copying it to host rectangles."""
+        ``ctx.pack_detections`` into an all-gather buffer) instead of copying it to host rectangles.
+        ``as_arrays``: configurations as (xy [n, 2] int32, marks [n, 3] float64) instead of lists of ``Rectangle``."""
         self.ctx.set_schedule(T0, alpha, T_target)
         wanted = list(snapshot_steps)[-num_samples:] if snapshot_steps else []
         samples = [[] for _ in self.tiles]
@@ -154,7 +156,7 @@ class TileBatchSampler:
                 on_device(self.ctx)
                 return
             for i, pts in enumerate(self.ctx.get_points_all()[:len(self.tiles)]):
-                samples[i].append(_to_rectangles(*pts))
+                samples[i].append(pts if as_arrays else _to_rectangles(*pts))
 
         done = 0
         self.kernel_ms = 0.0

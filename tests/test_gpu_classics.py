@@ -67,6 +67,22 @@ def test_contrast_values_device(t):
         assert np.all(got[empty] == E.CONTRAST_MEASURES[t][2])
 
 
+def test_contrast_q_fun_is_applied_to_the_measured_value():
+    """ContrastEnergy.q_fun (classics.py:109,162-163): applied by ``classic_values``; a term that carries one cannot be
+    part of a chain model (no callable crosses the C ABI)."""
+    base = term_for("craciun2", G["image"])
+    plain = E.classic_values(base, rects())
+    q = E.contrast_term("c", G["image"], dilation=2, gap=1, erode=1, contrast_measure_type="craciun2", rgb=True, thresh=0.25,
+                        q_fun=lambda v: 1.0 - 2.0 / (1.0 + np.exp(-v)))
+    got = E.classic_values(q, rects())
+    default = E.CONTRAST_MEASURES["craciun2"][2]
+    want = np.array([v if v == default else 1.0 - 2.0 / (1.0 + np.exp(-v)) for v in plain])
+    np.testing.assert_array_equal(got, want)
+    assert np.any(got != plain)
+    with pytest.raises(ValueError):
+        E.build_model_desc([q], [], None)
+
+
 @pytest.mark.parametrize("rgb", [True, False])
 def test_gradient_values_device(rgb):
     term = E.gradient_term("g", G["image"], dilation=1, rgb=rgb, thresh=0.1)

@@ -100,7 +100,7 @@ def test_config3_eight_512_tiles_in_one_context_equal_eight_oracle_chains():
         ties.append(check_tile_against_oracle(t.det, t.marks, setup, model, steps, seed, i, 1.0, 0.999, gxy, gm))
         assert matched_fraction(gxy, t.gt_xy) >= 0.97 and len(gxy) <= 1.03 * len(t.gt_xy)
     print("config 3: ties within the dE tolerance per 100 001-step chain:", ties)
-    assert max(ties) <= 50            # 70 000 of the steps run at T < 1e-13; a handful of zero-dE proposals tie
+    assert max(ties) <= 5             # 70 000 of the steps run at T < 1e-13; a handful (0 - 2) of zero-dE proposals tie
     # the all-gather's send buffer, packed on the device: records in tile order, image coordinates = tile + anchor
     import torch
     cap = 8 * 1024
