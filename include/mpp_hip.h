@@ -261,6 +261,17 @@ int mpp_shapenet_epilogue_nhwc(mpp_ctx *ctx, int H, int W, int ldh, int ldw, con
 int mpp_nhwc_glue(mpp_ctx *ctx, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad, int pool,
                   int in_bytes, int out_bytes, const float *scale, const float *shift);
 
+/* One Conv2d(C_in -> 32, kernel 3, padding 1, padding_mode='reflect') of a DoubleConv (model_parts/unet/unet_parts.py:12-31)
+ * on the matrix cores (v_mfma_f32_32x32x2_f32: float32 in, float32 accumulate), for the U-Nets' full-resolution level where
+ * the library's N = 32 kernels are slowest: x0 [H][W][32] float32 channels-last; x1 = NULL, or the second half of the
+ * concatenation cat([skip, up]) of `Up` (unet_parts.py:48-67) as a second [H][W][32] source (C_in = 64, no concatenated
+ * copy); wp [C_in / 32][3*3][32 in][32 out] = weight[o][32 s + i][kh][kw] repacked; in_scale / in_shift [32] (or both NULL):
+ * x0 <- max(0, x0 * in_scale + in_shift) at the load, i.e. the BatchNorm + ReLU of the layer that produced x0;
+ * y [H][W][32] <- (relu ? max(0, .) : .)(conv * out_scale + out_shift) with this layer's folded bias + BatchNorm (or both
+ * NULL).  Reflect padding is index arithmetic (no padded copy).  All device pointers, the ctx's stream. */
+int mpp_conv3x3_c32(mpp_ctx *ctx, const float *x0, const float *x1, int H, int W, const float *wp, const float *in_scale,
+                    const float *in_shift, const float *out_scale, const float *out_shift, int relu, float *y);
+
 /* IoU matrix of convex quadrilaterals for the DOTA task-1 evaluation: a [n][8], b [m][8] (x1 y1 .. x4 y4, either
  * orientation) -> out [n][m] = |A_i n B_j| / (|A_i| + |B_j| - |A_i n B_j|), or -1 where the axis-aligned extents
  * (inclusive-pixel +1 convention) do not overlap.  Stands in for `polyiou.iou_poly` and the hbb pre-filter of

@@ -44,6 +44,9 @@ extern "C" int mpp_launch_shapenet_epilogue_nhwc(hipStream_t st, const void *log
                                                  float *marks);
 extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *x1, void *y, int H, int W, int C0, int C1, int pad,
                                     int pool, int in_bytes, int out_bytes, const float *scale, const float *shift);
+extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const float *x1, int H, int W, const float *wp,
+                                      const float *in_scale, const float *in_shift, const float *out_scale, const float *out_shift,
+                                      int relu, float *y);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_pack_detections(hipStream_t st, const TileRef *tiles, int n_tiles, const int32_t *tile_ids,
                                            const int32_t *anchors, int capacity, double *out);
@@ -1170,6 +1173,16 @@ extern "C" int mpp_nhwc_glue(mpp_ctx *c, const void *x0, const void *x1, void *y
   HIPCHK(c, hipGetLastError());
   return 0;
 }
+extern "C" int mpp_conv3x3_c32(mpp_ctx *c, const float *x0, const float *x1, int H, int W, const float *wp, const float *in_scale,
+                               const float *in_shift, const float *out_scale, const float *out_shift, int relu, float *y) {
+  if (!c || !x0 || !wp || !y || H < 2 || W < 2 || (!in_scale) != (!in_shift) || (!out_scale) != (!out_shift))
+    return fail(c, -1, "bad conv3x3_c32 arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mpp_launch_conv3x3_c32(c->stream, x0, x1, H, W, wp, in_scale, in_shift, out_scale, out_shift, relu, y))
+    return fail(c, -2, "conv3x3_c32 launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
 extern "C" int mpp_quad_iou(mpp_ctx *c, int n, const double *a, int m, const double *b, double *out, int on_device) {
   if (!c || n < 0 || m < 0 || ((long long)n * m > 0 && (!a || !b || !out))) return fail(c, -1, "bad quad_iou arguments");
   if ((long long)n * m == 0) return 0;

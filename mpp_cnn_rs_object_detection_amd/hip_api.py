@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_image", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_merge_score", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_conv3x3_c32", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -116,6 +116,7 @@ def load_library(path: Optional[str] = None):
         "mpp_delta_batch": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
         "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
         "mpp_papangelou": (i32, [vp, i32, vp]),
+        "mpp_conv3x3_c32": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
         "mpp_merge_score": (i32, [vp, C.c_double, i32, vp, vp, vp, vp, vp]),
         "mpp_naive_init": (i32, [vp, dbl, dbl]),
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
@@ -521,6 +522,20 @@ class MppContext:
             out = out.permute(0, 3, 1, 2)
         self._check(self._L.mpp_nhwc_glue(self._h, _ptr(x0), _ptr(x1), _ptr(out), H, W, c0, c1, pad, 1 if pool else 0,
                                           int(x0.element_size()), int(out.element_size()), _ptr(scale), _ptr(shift)))
+        return out
+
+    def conv3x3_c32(self, x0, wp, x1=None, in_scale=None, in_shift=None, out_scale=None, out_shift=None, relu: bool = True, out=None):
+        """3x3 reflect-padded convolution to 32 channels on channels-last float32 activations (``mpp_conv3x3_c32``):
+        x0 (and x1, the second half of a concatenation): [1,32,H,W] CUDA tensors with channels_last strides; wp: the repacked
+        weights [C_in/32, 9, 32, 32]; returns relu(conv * out_scale + out_shift) as a [1,32,H,W] channels_last tensor."""
+        import torch
+        h, w, c = nhwc_shape(x0)
+        if c != 32 or x0.dtype != torch.float32 or (x1 is not None and nhwc_shape(x1) != (h, w, 32)):
+            raise ValueError("conv3x3_c32: float32 channels-last sources of 32 channels")
+        if out is None:
+            out = torch.empty((1, h, w, 32), dtype=torch.float32, device=x0.device).permute(0, 3, 1, 2)
+        self._check(self._L.mpp_conv3x3_c32(self._h, _ptr(x0), _ptr(x1), h, w, _ptr(wp), _ptr(in_scale), _ptr(in_shift),
+                                            _ptr(out_scale), _ptr(out_shift), 1 if relu else 0, _ptr(out)))
         return out
 
     # -- evaluation --------------------------------------------------------------------------------

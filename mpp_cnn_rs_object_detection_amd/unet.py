@@ -203,6 +203,7 @@ class ScoreMapNets:
         self.dtype = dtype
         self.ctx = ctx or MppContext(device)
         self.fused = os.environ.get("MPP_UNET_UNFUSED", "0") != "1"
+        self.mfma_conv = os.environ.get("MPP_UNET_MFMA_CONV", "1") != "0"      # csrc/mpp_conv.hip for the 32-channel level
         # below this many pixels the forward is launch-bound and the plain nn.Module path (fewer host calls) is faster:
         # 512x512 3.4 ms vs 4.8 ms; 2048x2048 41 ms (nchw) / 36 ms (nhwc) float32, 31 / 15 ms bfloat16
         self.min_fused_pixels = 1 << 20
@@ -244,10 +245,31 @@ class ScoreMapNets:
     def _cl(x: Tensor) -> Tensor:
         return x if x.is_contiguous(memory_format=torch.channels_last) else x.contiguous(memory_format=torch.channels_last)
 
+    def _packed(self, conv: nn.Conv2d) -> Tensor:
+        """weights of a Conv2d(C_in -> 32, 3x3) repacked for ``mpp_conv3x3_c32``: [C_in / 32][kh * 3 + kw][32 in][32 out]"""
+        key = (id(conv), "c32")
+        if key not in self._fold_cache:
+            w = conv.weight.detach().float()                                    # [32, C_in, 3, 3]
+            cin = w.shape[1]
+            self._fold_cache[key] = (w.permute(2, 3, 1, 0).reshape(9, cin // 32, 32, 32).permute(1, 0, 2, 3).contiguous(),)
+        return self._fold_cache[key][0]
+
     def _double_conv_nhwc(self, dc: DoubleConv, x0: Tensor, x1: Optional[Tensor] = None, pool: bool = False) -> Tensor:
         seq = dc.double_conv
         s1, t1 = self._folded(seq[0], seq[1])
         s2, t2 = self._folded(seq[3], seq[4])
+        # The 32-channel, full-resolution level in float32: the hand-written MFMA convolution (csrc/mpp_conv.hip) takes the
+        # unpadded activations (reflect padding is index arithmetic), the concat as a second source, the producer's
+        # BatchNorm + ReLU at the load and its own in the epilogue -- no glue pass around it.
+        c32 = (self.mfma_conv and self.dtype == torch.float32 and not pool and seq[0].out_channels == 32 and seq[3].in_channels == 32
+               and seq[3].out_channels == 32)
+        if c32 and seq[0].in_channels in (32, 64) and x0.shape[1] == 32 and (x1 is None) == (seq[0].in_channels == 32):
+            h = self.ctx.conv3x3_c32(x0, self._packed(seq[0]), x1=x1, out_scale=s1, out_shift=t1)
+            return self.ctx.conv3x3_c32(h, self._packed(seq[3]), out_scale=s2, out_shift=t2)
+        if c32 and x1 is None:                    # the stem (3 -> 32) by the library, its BatchNorm + ReLU at the next load
+            y = self.ctx.nhwc_glue(x0, None, pad=1, pool=False, out_dtype=self.dtype)
+            r = self._cl(F.conv2d(y, self._weights(seq[0])[0], None))
+            return self.ctx.conv3x3_c32(r, self._packed(seq[3]), in_scale=s1, in_shift=t1, out_scale=s2, out_shift=t2)
         y = self.ctx.nhwc_glue(x0, x1, pad=1, pool=pool, out_dtype=self.dtype)
         r = self._cl(F.conv2d(y, self._weights(seq[0])[0], None))
         y = self.ctx.nhwc_glue(r, pad=1, scale=s1, shift=t1)

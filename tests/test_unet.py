@@ -247,3 +247,37 @@ def test_channels_last_forward_matches_the_module_path(nets):
     for a, b in zip(marks_b, marks_u):
         assert float((a - b).abs().max()) < 0.08
         np.testing.assert_allclose(a.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,H,W", [(32, 64, 128), (64, 40, 72), (32, 17, 33), (64, 256, 320)])
+def test_mfma_conv3x3_c32_equals_the_library_convolution(cin, H, W):
+    """``mpp_conv3x3_c32`` (csrc/mpp_conv.hip): Conv2d(C_in -> 32, 3x3, reflect) + folded BatchNorm + ReLU of a DoubleConv
+    (unet_parts.py:12-31), the concat of Up as a second source, the producer's BatchNorm + ReLU at the load -- against
+    F.pad(mode='reflect') + F.conv2d in float32 (the summation order differs: 1e-4 relative)."""
+    import torch.nn.functional as F
+    from mpp_cnn_rs_object_detection_amd import hip_api
+    torch.manual_seed(cin + H)
+    dev = torch.device("cuda", 0)
+    ctx = hip_api.MppContext(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    x = torch.randn((1, cin, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((32, cin, 3, 3), device=dev) / (3.0 * cin ** 0.5)
+    sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    isc, ish = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    wp = w.permute(2, 3, 1, 0).reshape(9, cin // 32, 32, 32).permute(1, 0, 2, 3).contiguous()
+    x0 = x[:, :32].contiguous(memory_format=torch.channels_last)
+    x1 = x[:, 32:].contiguous(memory_format=torch.channels_last) if cin == 64 else None
+    for in_aff in (False, True):
+        xin = x.clone()
+        if in_aff:
+            xin[:, :32] = torch.relu(xin[:, :32] * isc.view(1, -1, 1, 1) + ish.view(1, -1, 1, 1))
+        ref = torch.relu(F.conv2d(F.pad(xin, (1, 1, 1, 1), mode="reflect"), w) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+        got = ctx.conv3x3_c32(x0, wp, x1=x1, in_scale=isc if in_aff else None, in_shift=ish if in_aff else None,
+                              out_scale=sc, out_shift=sh, relu=True)
+        torch.cuda.synchronize()
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # no epilogue: the raw convolution
+    raw = ctx.conv3x3_c32(x0, wp, x1=x1, relu=False)
+    np.testing.assert_allclose(raw.cpu().numpy(), F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w).cpu().numpy(), rtol=1e-4, atol=1e-5)
