@@ -36,6 +36,10 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {       // F.pad(mode='
 // x0, x1: [H][W][32] float32 (x1 = nullptr: 32 input channels); wp: [C_in / 32][9][32 in][32 out]; y: [H][W][32].
 // in_scale / in_shift (or nullptr): x0 <- max(0, x0 * in_scale[c] + in_shift[c]) at the load (the producer's BatchNorm + ReLU).
 // out_scale / out_shift (or nullptr) and relu: the epilogue.
+// Persistent workgroups: each takes a contiguous range of tiles; a "stage" = (tile, source); while the MFMAs of a stage run,
+// the 21 float4 a thread contributes to the NEXT stage's LDS tile are already on their way from HBM (registers); the
+// weights of both sources stay in LDS for the whole launch.
+#define CV_LD ((CV_TH * CV_TW * 8 + 255) / 256)               // float4 loads per thread and stage (21)
 __global__ __launch_bounds__(256, 1) void k_conv3x3_c32(const float *__restrict__ x0, const float *__restrict__ x1, int H, int W,
                                                         const float *__restrict__ wp, const float *__restrict__ in_scale,
                                                         const float *__restrict__ in_shift, const float *__restrict__ out_scale,
@@ -44,45 +48,64 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32(const float *__restrict_
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *tile = lds, *wl = lds + CV_TILE_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // consecutive workgroup ids go to different XCDs: give each XCD a contiguous range of tiles (neighbours share halo rows in L2)
-  const int per = (n_tiles + 7) / 8;
-  const int t = (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8);
-  if (t >= n_tiles) return;
-  const int ty = t / tiles_x, tx = t - ty * tiles_x;
-  const int r0 = ty * CV_ROWS, c0 = tx * CV_COLS;
+  const int n_src = x1 ? 2 : 1;
+  // consecutive workgroup ids go to different XCDs: workgroup (xcd, k) takes the k-th share of the xcd-th eighth of the tiles
+  // (neighbouring tiles share halo rows in that XCD's L2)
+  const int xcd = (int)(blockIdx.x % 8), k_in = (int)(blockIdx.x / 8), per_xcd = (int)(gridDim.x / 8);
+  const int e0 = (int)((long long)n_tiles * xcd / 8), e1 = (int)((long long)n_tiles * (xcd + 1) / 8);
+  const int t_begin = e0 + (int)((long long)(e1 - e0) * k_in / per_xcd), t_end = e0 + (int)((long long)(e1 - e0) * (k_in + 1) / per_xcd);
+  for (int q = tid; q < n_src * CV_W_FLOATS / 4; q += 256) *(float4 *)(wl + 4 * q) = *(const float4 *)(wp + 4 * q);
+  const int n_stage = (t_end - t_begin) * n_src;
+  if (n_stage <= 0) return;
+
+  float4 pre[CV_LD];
+  // the loads of stage `st` (tile t_begin + st / n_src, source st % n_src) into registers
+#define CV_ISSUE(st_)                                                                                                  \
+  do {                                                                                                                  \
+    const int t_ = t_begin + (st_) / n_src, ty_ = t_ / tiles_x, tx_ = t_ - ty_ * tiles_x;                               \
+    const float *x_ = ((st_) % n_src) == 0 ? x0 : x1;                                                                   \
+    _Pragma("unroll") for (int u = 0; u < CV_LD; ++u) {                                                                 \
+      const int q = tid + 256 * u, pix = q >> 3, j = q & 7;                                                             \
+      const int pr = pix / CV_TW, pc = pix - pr * CV_TW;                                                                \
+      const int gr = reflect_idx(min(ty_ * CV_ROWS - 1 + pr, H), H), gc = reflect_idx(min(tx_ * CV_COLS - 1 + pc, W), W); \
+      if (q < CV_TH * CV_TW * 8) pre[u] = *(const float4 *)(x_ + ((size_t)gr * W + gc) * 32 + 4 * j);                   \
+    }                                                                                                                   \
+  } while (0)
+  CV_ISSUE(0);
 
   f32x16 acc[4];
+  for (int st = 0; st < n_stage; ++st) {
+    const int src = st % n_src, t = t_begin + st / n_src;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int r0 = ty * CV_ROWS, c0 = tx * CV_COLS;
+    if (src == 0) {
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
-
-  const int n_src = x1 ? 2 : 1;
-  for (int s = 0; s < n_src; ++s) {
-    const float *x = s == 0 ? x0 : x1;
-    const bool aff = s == 0 && in_scale != nullptr;
-    if (s > 0) __syncthreads();                               // the previous pass has read its tile and weights
-    // ---- stage the input tile (with halo, reflected at the image border) and this pass's weights
-    for (int q = tid; q < CV_TH * CV_TW * 8; q += 256) {
-      const int pix = q >> 3, j = q & 7;
-      const int pr = pix / CV_TW, pc = pix - pr * CV_TW;
-      const int gr = reflect_idx(min(r0 - 1 + pr, H), H), gc = reflect_idx(min(c0 - 1 + pc, W), W);   // (beyond the image: any valid pixel)
-      float4 v = *(const float4 *)(x + ((size_t)gr * W + gc) * 32 + 4 * j);
-      if (aff) {
-        const float4 sc = *(const float4 *)(in_scale + 4 * j), sh = *(const float4 *)(in_shift + 4 * j);
-        v.x = fmaxf(0.f, v.x * sc.x + sh.x); v.y = fmaxf(0.f, v.y * sc.y + sh.y);
-        v.z = fmaxf(0.f, v.z * sc.z + sh.z); v.w = fmaxf(0.f, v.w * sc.w + sh.w);
-      }
-      float *d = tile + pix * CV_PIX + 4 * j;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        for (int i = 0; i < 16; ++i) acc[b][i] = 0.f;
     }
-    for (int q = tid; q < CV_W_FLOATS / 4; q += 256)
-      *(float4 *)(wl + 4 * q) = *(const float4 *)(wp + (size_t)s * CV_W_FLOATS + 4 * q);
+    __syncthreads();                                          // the previous stage has read its tile (and the weights are in)
+    const bool aff = src == 0 && in_scale != nullptr;
+#pragma unroll
+    for (int u = 0; u < CV_LD; ++u) {
+      const int q = tid + 256 * u, pix = q >> 3, j = q & 7;
+      if (q < CV_TH * CV_TW * 8) {
+        float4 v = pre[u];
+        if (aff) {
+          const float4 sc = *(const float4 *)(in_scale + 4 * j), sh = *(const float4 *)(in_shift + 4 * j);
+          v.x = fmaxf(0.f, v.x * sc.x + sh.x); v.y = fmaxf(0.f, v.y * sc.y + sh.y);
+          v.z = fmaxf(0.f, v.z * sc.z + sh.z); v.w = fmaxf(0.f, v.w * sc.w + sh.w);
+        }
+        float *d = tile + pix * CV_PIX + 4 * j;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      }
+    }
     __syncthreads();
+    if (st + 1 < n_stage) CV_ISSUE(st + 1);                   // in flight while the MFMAs below run
     // ---- 9 taps x 16 channel pairs: one B fragment, four A fragments, four MFMAs
     const int m = lane & 31, kh = lane >> 5;
     const float *arow = tile + ((2 * wave) * CV_TW + m) * CV_PIX + kh;       // block b: row 2*wave + (b >> 1), columns 32*(b & 1) + m
-    const float *bw = wl + kh * 32 + m;
+    const float *bw = wl + src * CV_W_FLOATS + kh * 32 + m;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap % 3;
@@ -96,21 +119,23 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32(const float *__restrict_
         }
       }
     }
-  }
-  // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
-  const int n = lane & 31;
-  const float sc = out_scale ? out_scale[n] : 1.f, sh = out_shift ? out_shift[n] : 0.f;
+    if (src + 1 < n_src) continue;
+    // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
+    const int n = lane & 31;
+    const float sc = out_scale ? out_scale[n] : 1.f, sh = out_shift ? out_shift[n] : 0.f;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int row = r0 + 2 * wave + (b >> 1);
+    for (int b = 0; b < 4; ++b) {
+      const int row = r0 + 2 * wave + (b >> 1);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int col = c0 + 32 * (b & 1) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      float v = acc[b][i] * sc + sh;
-      if (relu) v = fmaxf(0.f, v);
-      if (row < H && col < W) y[((size_t)row * W + col) * 32 + n] = v;
+      for (int i = 0; i < 16; ++i) {
+        const int col = c0 + 32 * (b & 1) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        float v = acc[b][i] * sc + sh;
+        if (relu) v = fmaxf(0.f, v);
+        if (row < H && col < W) y[((size_t)row * W + col) * 32 + n] = v;
+      }
     }
   }
+#undef CV_ISSUE
 }
 
 extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const float *x1, int H, int W, const float *wp,
@@ -118,13 +143,18 @@ extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const flo
                                       int relu, float *y) {
   if (H < 2 || W < 2) return -1;
   const int tiles_x = (W + CV_COLS - 1) / CV_COLS, tiles_y = (H + CV_ROWS - 1) / CV_ROWS, n_tiles = tiles_x * tiles_y;
-  const size_t lds = (size_t)(CV_TILE_FLOATS + CV_W_FLOATS) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void *)k_conv3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
-    attr = true;
+  const size_t lds = (size_t)(CV_TILE_FLOATS + (x1 ? 2 : 1) * CV_W_FLOATS) * sizeof(float);
+  // one workgroup per CU (its LDS footprint allows no more), eight at a time to the eight XCDs
+  static int cus = 0;                                   // (queried once: hipGetDeviceProperties costs about a millisecond)
+  if (cus == 0) {
+    if (hipFuncSetAttribute((const void *)k_conv3x3_c32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(CV_TILE_FLOATS + 2 * CV_W_FLOATS) * 4) != hipSuccess) return -2;
+    int dev = 0, n = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
   }
-  const int grid = ((n_tiles + 7) / 8) * 8;
+  int grid = (cus / 8) * 8;
+  if (grid > ((n_tiles + 7) / 8) * 8) grid = ((n_tiles + 7) / 8) * 8;
+  if (grid < 8) grid = 8;
   hipLaunchKernelGGL(k_conv3x3_c32, dim3(grid), dim3(256), lds, st, x0, x1, H, W, wp, in_scale, in_shift, out_scale, out_shift, relu, y,
                      tiles_x, n_tiles);
   return hipGetLastError() == hipSuccess ? 0 : -2;
