@@ -21,7 +21,7 @@ extern "C" size_t mpp_deep_static_lds_bytes(int waves);
 extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
-                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats);
+                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats, int ext);
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
                                             double *dE);
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int cap, const double *dE, int dist2,
@@ -995,7 +995,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     const bool fast = M.n_pair == 2 && M.pair[0].kind == MPP_P_OVERLAP && M.pair[0].reduce == MPP_REDUCE_MAX &&
                       M.pair[1].kind == MPP_P_ALIGN && M.pair[1].reduce == MPP_REDUCE_MIN;
     if (c->deep > 0 && c->lanes == 0 && c->spec <= 8 && !d_tape && fast && c->hp.n_kernels <= MPP_K_SPLIT &&
-        !has_classic(M) && !c->hp.force_accept) {
+        (!has_classic(M) || c->spec == 1 || c->spec == 8) && !c->hp.force_accept && c->hp.nx < 256 && c->hp.ny < 256) {
       deep_nmax = c->deep < 64 * c->spec ? c->deep : 64 * c->spec;
       if (deep_nmax < c->spec) deep_nmax = c->spec;
       if (c->H <= 1024) c->hp.rowbase_lds = 1;
@@ -1036,7 +1036,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
       int fixed = c->deep_fixed > nmax ? nmax : c->deep_fixed;
       if (fixed > 0) { fixed = fixed / c->spec * c->spec; if (fixed < c->spec) fixed = c->spec; }
       HIPCHK(c, mpp_launch_deep(c->stream, c->spec, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed, chain0,
-                                trace_tile, d_out, d_props, nmax, fixed, c->deep_gain, c->deep_stats));
+                                trace_tile, d_out, d_props, nmax, fixed, c->deep_gain, c->deep_stats, has_classic(c->hp.model) ? 1 : 0));
     } else
     HIPCHK(c, mpp_launch_chain(c->stream, c->spec, c->lanes, occ, grid, lds, &c->hp, c->d_tiles, tile0, c->until, trace_base, seed,
                                chain0, d_tape, trace_tile, d_out, d_props));

@@ -1326,7 +1326,7 @@ __device__ __forceinline__ void draw_proposal(const Chain &c, const uint32_t w[8
 
 // n-independent parts of the forward / backward proposal probabilities.  The symmetric Gaussian
 // kernels have qf == qb, which cancels in the Green ratio: their pdf is evaluated only for traces.
-__device__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep, bool coop) {
+__device__ __forceinline__ void proposal_densities(const Chain &c, Rec &r, bool tracing, int keep, bool coop) {
   const DevParams *P = c.P;
   if (keep & KEEP_QF) { r.qb = 1.0; return; }
   if (keep & KEEP_QFB) return;

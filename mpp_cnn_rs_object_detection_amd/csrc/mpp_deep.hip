@@ -62,12 +62,13 @@ struct DeepLds {
   unsigned short *poff;        // [nmax] sorted position -> offset of the step in the round
   unsigned short *tcnt;        // [WAVES][16] steps of each kernel type per wave
   double *tring;               // [4 * nmax] temperature of step (offset & mask), filled two rounds ahead
-  unsigned long long *racc;    // [WAVES][2][64] per step of a wave: max of the overlaps / min of the alignments with the added point
+  unsigned long long *racc;    // [WAVES][3][64] per step of a wave: max of the overlaps / min of the alignments with the added point;
+                               // a candidate neighbour of the step has a non-finite energy (classic image energies only)
   unsigned int *clist;         // [WAVES][DEEP_CLIST] (step << 16 | slot): the neighbours in range of a wave's steps, in order
   unsigned char *ltab;         // [WAVES][128] the 3 x 3 blocks of cells a wave's steps look at (lane | 0x80: the added point's)
 };
 __host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
-  return (size_t)nmax * 16 + (size_t)4 * nmax * 8 + (size_t)waves * 2 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
+  return (size_t)nmax * 16 + (size_t)4 * nmax * 8 + (size_t)waves * 3 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
          (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 128 + 64;
 }
 __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
@@ -77,7 +78,7 @@ __device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
   DeepLds D;
   D.pw = (uint4 *)base; base += (size_t)nmax * 16;
   D.tring = (double *)base; base += (size_t)4 * nmax * 8;
-  D.racc = (unsigned long long *)base; base += (size_t)waves * 2 * 64 * 8;
+  D.racc = (unsigned long long *)base; base += (size_t)waves * 3 * 64 * 8;
   D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
   D.info = (uint4 *)base; base += (size_t)nmax * 16;
   D.nb = (uint2 *)base; base += (size_t)nmax * 8;
@@ -132,6 +133,7 @@ __device__ __forceinline__ void write_slot_1(const Chain &c, int slot, const Rec
 // evaluate() of mpp_chain.hpp in its lane form, in two halves around the ONE call of eval_delta_lane the kernel has (the
 // step's evaluation and, for a step that commits, the second pass that writes the neighbours' reductions go through the
 // same call site: with two, the inliner leaves a real call behind and the chain state lives in scratch memory)
+template <bool EXT>
 __device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool tracing, const MapVals &pmv) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
@@ -155,7 +157,7 @@ __device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool 
     if (keep & KEEP_TRIG) { g.ca = L.ca[r.tslot]; g.sa = L.sa[r.tslot]; }
     else if (keep & KEEP_EDGE_ANGLE) { g.ca = L.trig[r.acls]; g.sa = L.trig[MPP_NCLASS + r.acls]; }
     else { double al = add.a + MPP_PI / 2.0; g.ca = cos(al); g.sa = sin(al); }
-    unit_part_mv<false>(P, c.t, mv, add, g, &r.lin_a, &r.gate_a, nullptr, false);
+    unit_part_mv<EXT>(P, c.t, mv, add, g, &r.lin_a, &r.gate_a, nullptr, false);
     r.hl = g.hl; r.hw = g.hw; r.ca = g.ca; r.sa = g.sa; r.rad = rad;
   }
 }
@@ -257,13 +259,14 @@ __device__ __forceinline__ double clip_area_groups(const Chain &c, bool gact, co
 //      itself (max / min: order-free) are LDS atomics on the bit patterns.
 // `apply` (wave-uniform): the changed reductions are written to the caches (the second pass of a step that commits).
 // Model: pair 0 = rectangle overlap / max, pair 1 = alignment / min (FAST).
+template <bool EXT>
 __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, bool lead, bool has_rem, bool has_add, int rem,
                                            int rxy, int axy, double a_s, double a_r, double a_a, double a_hl, double a_hw,
                                            double a_ca, double a_sa, double a_rad, bool apply, double *sum_out, double *ra0_out,
-                                           double *ra1_out, int *nchg_out, int *nb0_out, int *nb1_out, int *nresc_out, int *su_out, double *sv_out DPH_ARGS) {
+                                           double *ra1_out, int *nchg_out, int *nb0_out, int *nb1_out, int *nresc_out, int *su_out, double *sv_out, bool *nonfinite_out DPH_ARGS) {
   const Lds &L = c.L;
   unsigned int *clist = D.clist + (size_t)c.wave * DEEP_CLIST;
-  unsigned long long *racc = D.racc + (size_t)c.wave * 128;
+  unsigned long long *racc = D.racc + (size_t)c.wave * 192;
   const int flags = (lead ? 4 : 0) | (lead && has_rem ? 1 : 0) | (lead && has_add ? 2 : 0);
   const int maxd2_0 = c.pr0.maxd2, maxd2_1 = c.pr1.maxd2, range2 = maxd2_0 > maxd2_1 ? maxd2_0 : maxd2_1;
   const double rew = c.pr1.p0 != 0.0 ? 1.0 : 0.0;
@@ -285,6 +288,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
     ntasks = 9 * npos;
   }
   racc[c.lane] = 0ull; racc[64 + c.lane] = 0ull;
+  if (EXT) racc[128 + c.lane] = 0ull;
   wave_lds_fence();
   double sum = 0.0;
   int nchg = 0, M = 0, t0 = 0, nb0 = 0, nb1 = 0, nresc = 0, su = 0;
@@ -325,6 +329,16 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
             for (int q = 0; q < 4; ++q) u_[q] = e0 + q < cnt ? (int)L.cell_items[base + e0 + q] : 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) xy_[q] = e0 + q < cnt ? L.xy[u_[q]] : 0;
+            if (EXT) {
+              // a candidate neighbour (ANY entry of the cells looked at, as eval_delta's generic form does) whose own energy is
+              // not finite makes the reference's E(after) - E(before) over the neighbourhood inf - inf = NaN
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (e0 + q < cnt && u_[q] != (s_hr ? srem : -1)) {
+                  const double lu = L.lin[u_[q]];
+                  if (!(lu - lu == 0.0)) racc[128 + i] = 1ull;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int ux = xy_[q] & 0xffff, uy = (xy_[q] >> 16) & 0xffff;
@@ -639,6 +653,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   *su_out = su; sv_out[0] = sv00; sv_out[1] = sv01; sv_out[2] = sv10; sv_out[3] = sv11;
   *ra0_out = __longlong_as_double((long long)racc[c.lane]);
   *ra1_out = __longlong_as_double((long long)racc[64 + c.lane]);
+  *nonfinite_out = EXT && racc[128 + c.lane] != 0ull;
 }
 
 // the state change of a committed step, done by the lane that evaluated it (n: the population at the round's start)
@@ -667,7 +682,8 @@ __device__ __forceinline__ void deep_mutate(const Chain &c, const Rec &r, int n,
 }
 __device__ __forceinline__ unsigned long long low_mask(int k) { return k <= 0 ? 0ull : (k >= 64 ? ~0ull : ((1ull << k) - 1ull)); }
 
-template <int WAVES, bool DIAG, int OCC, bool FAST>
+// EXT: the instantiation that knows the classic image energies (mpp_classics.hpp): every lane rasterises its own rectangle
+template <int WAVES, bool DIAG, int OCC, bool EXT>
 __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevParams Pv, const TileRef *tiles, int tile0,
                                                                  const long long *until, long long trace_base,
                                                                  unsigned long long seed, unsigned int chain0, int trace_tile,
@@ -708,7 +724,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     Rect q{c.t.px[i], c.t.py[i], c.t.ps[i], c.t.pr[i], c.t.pa[i]};
     Geo g = make_geo(q);
     double lin; int gate;
-    unit_part<false>(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
+    unit_part<EXT>(P, c.t, L.edges, q, g, &lin, &gate, nullptr);
     L.xy[i] = (q.x & 0xffff) | (q.y << 16);
     L.s[i] = q.s; L.r[i] = q.r; L.a[i] = q.a; L.ca[i] = g.ca; L.sa[i] = g.sa; L.hl[i] = g.hl; L.hw[i] = g.hw;
     L.rad[i] = geo_radius(g);
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       DPH(3);
       if (r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
       if (r.valid && r.has_add && (r.ax < 0 || r.ax >= c.h.H || r.ay < 0 || r.ay >= c.h.W)) { r.valid = 0; r.kernel = -1; }
-      if (r.valid) deep_pre(c, r, keep, tracing, pmv);
+      if (r.valid) deep_pre<EXT>(c, r, keep, tracing, pmv);
     }
     do_eval = mine && r.valid && (r.has_rem || r.has_add);
     DPH(4);
@@ -864,13 +880,15 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     {
       double ra0 = 0.0, ra1 = 0.0, sde = 0.0, sv[4];
       int ns = 0, nresc = 0, su = 0;
+      bool nonf = false;
       const bool hr = r.has_rem != 0, ha = r.has_add != 0;
-      deep_delta(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
-                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns, &nb0, &nb1, &nresc, &su, sv DPH_PASS);
+      deep_delta<EXT>(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
+                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns, &nb0, &nb1, &nresc, &su, sv, &nonf DPH_PASS);
       if (stage == 1 && do_eval) {
         double dE = sde;
         if (ha) dE += finish_energy_c(c, r.lin_a + pair_part_c(c, r.gate_a, ra0, ra1));
         if (hr) dE -= finish_energy_c(c, L.lin[r.tslot] + pair_part_c(c, (int)L.gate[r.tslot], L.red0[r.tslot], L.red1[r.tslot]));
+        if (EXT && nonf) dE = nan("");
         r.dE = dE; r.ra0 = ra0; r.ra1 = ra1; r.n_stash = ns; r._pad2 = nresc;
         if (ns > 0 && ns <= 2) {                 // (kept for the commit: written by this lane again, read by no other)
           double *st = D.st + (size_t)5 * myoff;
@@ -1113,33 +1131,41 @@ extern "C" size_t mpp_deep_static_lds_bytes(int waves) {
   return waves >= MPP_LDS_PARAMS_MIN_WAVES ? ((sizeof(DevParams) + 15) & ~(size_t)15) : 0;
 }
 
-template <int WAVES, bool DIAG, int OCC>
+template <int WAVES, bool DIAG, int OCC, bool EXT>
 static hipError_t launch_deep_d(hipStream_t st, int grid, size_t lds, const DevParams *P, const TileRef *tiles, int tile0,
                                 const long long *until, long long trace_base, unsigned long long seed, unsigned int chain0,
                                 int trace_tile, mpp_step_out *out, mpp_proposal *props, int nmax, int fixed_depth, int gain8,
                                 unsigned long long *stats) {
-  hipError_t e = hipFuncSetAttribute((const void *)mpp_deep_kernel<WAVES, DIAG, OCC, true>,
+  hipError_t e = hipFuncSetAttribute((const void *)mpp_deep_kernel<WAVES, DIAG, OCC, EXT>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((mpp_deep_kernel<WAVES, DIAG, OCC, true>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0, until,
+  hipLaunchKernelGGL((mpp_deep_kernel<WAVES, DIAG, OCC, EXT>), dim3(grid), dim3(WAVE * WAVES), lds, st, *P, tiles, tile0, until,
                      trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats);
   return hipGetLastError();
 }
 
-// waves = waves per chain (1, 2, 4, 8); nmax = most steps of one round (a power of two, waves <= nmax <= 64 * waves, <= 512)
+// waves = waves per chain (1, 2, 4, 8); nmax = most steps of one round (a power of two, waves <= nmax <= 64 * waves, <= 256);
+// ext: a classic image energy among the unit terms (built for 1 and 8 waves, like the one-wave-per-step kernels)
 extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
-                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats) {
+                                      mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats, int ext) {
   const bool diag = out || props;
-#define GO(W, O)                                                                                                          \
-  return diag ? launch_deep_d<W, true, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats) \
-              : launch_deep_d<W, false, O>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats)
+#define GO(W, O, X)                                                                                                       \
+  return diag ? launch_deep_d<W, true, O, X>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats) \
+              : launch_deep_d<W, false, O, X>(st, grid, lds, P, tiles, tile0, until, trace_base, seed, chain0, trace_tile, out, props, nmax, fixed_depth, gain8, stats)
+  if (ext) {
+    switch (waves) {
+      case 1: GO(1, 1, true);
+      case 8: GO(8, 2, true);
+    }
+    return hipErrorNotSupported;
+  }
   switch (waves) {
-    case 1: if (occ >= 2) { GO(1, 2); } GO(1, 1);
-    case 2: if (occ >= 2) { GO(2, 2); } GO(2, 1);
-    case 4: if (occ >= 2) { GO(4, 2); } GO(4, 1);
-    case 8: GO(8, 2);
+    case 1: if (occ >= 2) { GO(1, 2, false); } GO(1, 1, false);
+    case 2: if (occ >= 2) { GO(2, 2, false); } GO(2, 1, false);
+    case 4: if (occ >= 2) { GO(4, 2, false); } GO(4, 1, false);
+    case 8: GO(8, 2, false);
   }
 #undef GO
   return hipErrorInvalidValue;
