@@ -16,7 +16,7 @@ extern "C" hipError_t mpp_launch_chain(hipStream_t st, int spec, int lanes, int 
                                        const DevParams *P, const TileRef *tiles, int tile0, const long long *until,
                                        long long trace_base, unsigned long long seed, unsigned int chain0, const mpp_proposal *tape,
                                        int trace_tile, mpp_step_out *out, mpp_proposal *props);
-extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax);
+extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax, int ext);
 extern "C" size_t mpp_deep_static_lds_bytes(int waves);
 extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int grid, size_t lds, const DevParams *P,
                                       const TileRef *tiles, int tile0, const long long *until, long long trace_base,
@@ -289,6 +289,7 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else return fail(c, -1, "unknown option %s", name);
   return 0;
 }
+static bool has_classic(const mpp_model &M, int *want_gradient);
 extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!c || !name) return -1;
   if (!strcmp(name, "spec_waves")) return c->spec;
@@ -322,7 +323,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
                mpp_chain_static_lds_bytes(c->lanes > 0 ? 4 : c->spec);
     if (c->deep > 0 && c->lanes == 0 && c->spec <= 8) {        // deep rounds: at least the smallest round has to fit
       const int rbd = c->H <= 1024 ? c->H + 1 : 0;
-      const size_t d = mpp_deep_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, rbd, c->spec, c->spec > 8 ? c->spec : 8) +
+      const size_t d = mpp_deep_lds_bytes(c->cap, ncell > 0 ? ncell : 1, c->cell_cap, rbd, c->spec, c->spec > 8 ? c->spec : 8, has_classic(c->hp.model, nullptr) ? 1 : 0) +
                        mpp_deep_static_lds_bytes(c->spec);
       if (d > b) b = d;
     }
@@ -1021,12 +1022,12 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     size_t lds = chain_lds(c, c->cap, c->cell_cap);
     // deep rounds need room for their step reports next to the chain state: halve the round until it fits, or do without
     int nmax = deep_nmax;
-    const int ncell_ = c->hp.nx * c->hp.ny, rb_ = c->hp.rowbase_lds ? c->H + 1 : 0;
+    const int ncell_ = c->hp.nx * c->hp.ny, rb_ = c->hp.rowbase_lds ? c->H + 1 : 0, ext_ = has_classic(c->hp.model) ? 1 : 0;
     while (nmax >= c->spec && nmax > 0 &&
-           mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax) + mpp_deep_static_lds_bytes(c->spec) > MPP_LDS_LIMIT)
+           mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_) + mpp_deep_static_lds_bytes(c->spec) > MPP_LDS_LIMIT)
       nmax /= 2;
     if (nmax < c->spec || nmax < 8) nmax = 0;
-    if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax);
+    if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_);
     else if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
                   lds, MPP_LDS_LIMIT);

@@ -55,7 +55,8 @@
 
 struct DeepLds {
   uint4 *info;                 // [nmax] (flags | slot, removed xy, added xy, cell coordinates) -- indexed by the step's offset in the round
-  uint2 *nb;                   // [nmax] positions of the (at most two) neighbours whose cached reductions the step changes
+  uint4 *nb;                   // [nmax] positions (and circumradii, rounded up) of the (at most two) neighbours whose cached
+                               // reductions the step changes
   double *st;                  // [nmax][5] ... and their new reductions (2 x 2 values, then the two slots as bits): a step that
                                // commits writes them; only a step that changes more than two neighbours needs a second pass
   uint4 *pw;                   // [nmax] Philox block 0 of the steps, in sorted order
@@ -67,21 +68,21 @@ struct DeepLds {
   unsigned int *clist;         // [WAVES][DEEP_CLIST] (step << 16 | slot): the neighbours in range of a wave's steps, in order
   unsigned char *ltab;         // [WAVES][128] the 3 x 3 blocks of cells a wave's steps look at (lane | 0x80: the added point's)
 };
-__host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves) {
-  return (size_t)nmax * 16 + (size_t)4 * nmax * 8 + (size_t)waves * 3 * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 24 + (size_t)nmax * 40 +
+__host__ __device__ inline size_t deep_extra_bytes(int nmax, int waves, int ext) {
+  return (size_t)nmax * 16 + (size_t)4 * nmax * 8 + (size_t)waves * (2 + (ext ? 1 : 0)) * 64 * 8 + (size_t)waves * DEEP_CLIST * 4 + (size_t)nmax * 32 + (size_t)nmax * 40 +
          (size_t)nmax * 2 + (size_t)waves * 16 * 2 + (size_t)waves * 128 + 64;
 }
 __host__ __device__ inline size_t deep_base_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves) {
   return (lds_bytes(cap, ncell, cell_cap, 0, rowbase_n, waves) + 15) & ~(size_t)15;
 }
-__device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves) {
+__device__ inline DeepLds deep_carve(unsigned char *base, int nmax, int waves, int ext) {
   DeepLds D;
   D.pw = (uint4 *)base; base += (size_t)nmax * 16;
   D.tring = (double *)base; base += (size_t)4 * nmax * 8;
-  D.racc = (unsigned long long *)base; base += (size_t)waves * 3 * 64 * 8;
+  D.racc = (unsigned long long *)base; base += (size_t)waves * (2 + (ext ? 1 : 0)) * 64 * 8;
   D.clist = (unsigned int *)base; base += (size_t)waves * DEEP_CLIST * 4;
   D.info = (uint4 *)base; base += (size_t)nmax * 16;
-  D.nb = (uint2 *)base; base += (size_t)nmax * 8;
+  D.nb = (uint4 *)base; base += (size_t)nmax * 16;
   D.st = (double *)base; base += (size_t)nmax * 40;
   D.poff = (unsigned short *)base; base += (size_t)nmax * 2;
   D.tcnt = (unsigned short *)base; base += (size_t)waves * 16 * 2;
@@ -263,10 +264,10 @@ template <bool EXT>
 __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, bool lead, bool has_rem, bool has_add, int rem,
                                            int rxy, int axy, double a_s, double a_r, double a_a, double a_hl, double a_hw,
                                            double a_ca, double a_sa, double a_rad, bool apply, double *sum_out, double *ra0_out,
-                                           double *ra1_out, int *nchg_out, int *nb0_out, int *nb1_out, int *nresc_out, int *su_out, double *sv_out, bool *nonfinite_out DPH_ARGS) {
+                                           double *ra1_out, int *nchg_out, int *nb0_out, int *nb1_out, int *nbr_out, int *nresc_out, int *su_out, double *sv_out, bool *nonfinite_out DPH_ARGS) {
   const Lds &L = c.L;
   unsigned int *clist = D.clist + (size_t)c.wave * DEEP_CLIST;
-  unsigned long long *racc = D.racc + (size_t)c.wave * 192;
+  unsigned long long *racc = D.racc + (size_t)c.wave * (EXT ? 192 : 128);
   const int flags = (lead ? 4 : 0) | (lead && has_rem ? 1 : 0) | (lead && has_add ? 2 : 0);
   const int maxd2_0 = c.pr0.maxd2, maxd2_1 = c.pr1.maxd2, range2 = maxd2_0 > maxd2_1 ? maxd2_0 : maxd2_1;
   const double rew = c.pr1.p0 != 0.0 ? 1.0 : 0.0;
@@ -291,7 +292,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
   if (EXT) racc[128 + c.lane] = 0ull;
   wave_lds_fence();
   double sum = 0.0;
-  int nchg = 0, M = 0, t0 = 0, nb0 = 0, nb1 = 0, nresc = 0, su = 0;
+  int nchg = 0, M = 0, t0 = 0, nb0 = 0, nb1 = 0, nbr = 0, nresc = 0, su = 0;
   double sv00 = 0.0, sv01 = 0.0, sv10 = 0.0, sv11 = 0.0;       // new reductions of the first two neighbours that change
   bool pending = false;
   int p_cnt = 0, p_base[2] = {0, 0}, p_i[2] = {0, 0};
@@ -634,10 +635,11 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
           const int uxy = __builtin_amdgcn_readlane((gu.g.x & 0xffff) | (gu.g.y << 16), src);
           const int uu = __builtin_amdgcn_readlane(u, src);
           const double w0 = readlane_d(nv0, src), w1 = readlane_d(nv1, src);
+          const int ur = (int)ceil(readlane_d(gu.rad, src));          // its circumradius, rounded up
           if (c.lane == is) {
             sum += v;
-            if (nchg == 0) { nb0 = uxy; su = uu; sv00 = w0; sv01 = w1; }
-            else if (nchg == 1) { nb1 = uxy; su |= uu << 16; sv10 = w0; sv11 = w1; }
+            if (nchg == 0) { nb0 = uxy; nbr = ur & 0xff; su = uu; sv00 = w0; sv01 = w1; }
+            else if (nchg == 1) { nb1 = uxy; nbr |= (ur & 0xff) << 8; su |= uu << 16; sv10 = w0; sv11 = w1; }
             nchg += 1;
           }
         }
@@ -649,7 +651,7 @@ __device__ __forceinline__ void deep_delta(const Chain &c, const DeepLds &D, boo
     if (final) break;
   }
   wave_lds_fence();
-  *sum_out = sum; *nchg_out = nchg; *nb0_out = nb0; *nb1_out = nb1; *nresc_out = nresc;
+  *sum_out = sum; *nchg_out = nchg; *nb0_out = nb0; *nb1_out = nb1; *nbr_out = nbr; *nresc_out = nresc;
   *su_out = su; sv_out[0] = sv00; sv_out[1] = sv01; sv_out[2] = sv10; sv_out[3] = sv11;
   *ra0_out = __longlong_as_double((long long)racc[c.lane]);
   *ra1_out = __longlong_as_double((long long)racc[64 + c.lane]);
@@ -700,7 +702,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   const int ncell = P->nx * P->ny, cap = P->cap;
   const int rowbase_n = P->rowbase_lds ? P->H + 1 : 0;
   c.L = carve(lds_raw, cap, ncell, P->cell_cap, 0, rowbase_n, WAVES);
-  const DeepLds D = deep_carve(lds_raw + deep_base_bytes(cap, ncell, P->cell_cap, rowbase_n, WAVES), nmax, WAVES);
+  const DeepLds D = deep_carve(lds_raw + deep_base_bytes(cap, ncell, P->cell_cap, rowbase_n, WAVES), nmax, WAVES, EXT ? 1 : 0);
   c.lane = threadIdx.x & (WAVE - 1);
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x / WAVE);
   const Lds &L = c.L;
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
   r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r._pad = 0; r.tslot = -1; r.tidx = -1;
   r.ax = r.ay = r.rx = r.ry = 0; r.as = r.ar = r.aa = 0.0; r.hl = r.hw = r.ca = r.sa = r.rad = 0.0; r.lin_a = 0.0; r.gate_a = 1;
   bool mine = false, my_commit = false;
-  int myoff = 0, lim = 0, committed = 0, cur_n = n, nb0 = 0, nb1 = 0, ring_todo = 0;
+  int myoff = 0, lim = 0, committed = 0, cur_n = n, nb0 = 0, nb1 = 0, nbr = 0, ring_todo = 0;
   long long ring_from = 0;
   double Tm = 0.0;
   while (stage == 0 || (done < n_steps && err == 0)) {
@@ -883,7 +885,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       bool nonf = false;
       const bool hr = r.has_rem != 0, ha = r.has_add != 0;
       deep_delta<EXT>(c, D, do_eval, hr, ha, hr ? r.tslot : -1, (r.rx & 0xffff) | (r.ry << 16), (r.ax & 0xffff) | (r.ay << 16), r.as,
-                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns, &nb0, &nb1, &nresc, &su, sv, &nonf DPH_PASS);
+                 r.ar, r.aa, r.hl, r.hw, r.ca, r.sa, r.rad, stage == 0, &sde, &ra0, &ra1, &ns, &nb0, &nb1, &nbr, &nresc, &su, sv, &nonf DPH_PASS);
       if (stage == 1 && do_eval) {
         double dE = sde;
         if (ha) dE += finish_energy_c(c, r.lin_a + pair_part_c(c, r.gate_a, ra0, ra1));
@@ -921,7 +923,11 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
                     (chg && r.n_stash > 1 ? DI_NB2 : 0) | (chg && r.n_stash > 2 ? DI_NBOV : 0) | (r.valid && r._pad2 > 0 ? DI_RESC : 0);
       D.info[myoff] = make_uint4((unsigned)f, (unsigned)((r.rx & 0xffff) | (r.ry << 16)), (unsigned)((r.ax & 0xffff) | (r.ay << 16)),
                                  (unsigned)(ci_r | (cj_r << 8) | (ci_a << 16) | (cj_a << 24)));
-      if (chg) D.nb[myoff] = make_uint2((unsigned)nb0, (unsigned)nb1);
+      // circumradius (rounded up, at most 255) of the largest rectangle the step removes or adds: how far its overlap term reaches
+      double rr = r.has_add ? r.rad : 0.0;
+      if (r.has_rem) { const double r0_ = L.rad[r.tslot]; rr = r0_ > rr ? r0_ : rr; }
+      const int own_r = rr < 254.0 ? (int)ceil(rr) : 255;
+      D.nb[myoff] = make_uint4((unsigned)nb0, (unsigned)nb1, (unsigned)nbr, (unsigned)own_r);
     }
     // temperatures of the steps that entered the window with the PREVIOUS round's commit (the ring is two rounds ahead; wave 0
     // runs the cheapest kernels and would wait at the barrier anyway): one multiply per step, in step order, as the chain does
@@ -944,16 +950,17 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     //      a cell list of o's 3 x 3 blocks (q crosses a cell border: the order of that cell's entries changes);
     //      and, when o re-reduced a neighbour, anything within twice the range.  A birth / death ends the round.
     uint4 o_[NCH];
+    int or_[NCH];                               // reach radius of the report's rectangles
     bool ok_[NCH];
     unsigned long long am_[NCH], cm_[NCH];
     const int nch = (lim + 63) >> 6;            // chunks in use
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
-      o_[ch] = make_uint4(0u, 0u, 0u, 0u); ok_[ch] = false; am_[ch] = 0ull; cm_[ch] = 0ull;
+      o_[ch] = make_uint4(0u, 0u, 0u, 0u); or_[ch] = 0; ok_[ch] = false; am_[ch] = 0ull; cm_[ch] = 0ull;
       if (ch < nch) {
         const int idx = ch * 64 + c.lane;
         const bool in = idx < lim;
-        if (in) o_[ch] = D.info[idx];
+        if (in) { o_[ch] = D.info[idx]; or_[ch] = (int)D.nb[idx].w; }
         ok_[ch] = in && (o_[ch].x & DI_VALID);
         am_[ch] = __ballot(in && (o_[ch].x & DI_CHG));
       }
@@ -1010,10 +1017,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       const int qci[2] = {(int)(q.w & 0xffu), (int)((q.w >> 16) & 0xffu)}, qcj[2] = {(int)((q.w >> 8) & 0xffu), (int)(q.w >> 24)};
       const bool q_cross = qci[0] != qci[1] || qcj[0] != qcj[1];
       const bool q_far = (qf & DI_NBOV) != 0;
-      int qnx[2] = {0, 0}, qny[2] = {0, 0}, q_nnb = 0;
+      int qnx[2] = {0, 0}, qny[2] = {0, 0}, qnr[2] = {0, 0}, q_nnb = 0;
+      const uint4 qn = D.nb[wq];
+      const int q_r = (int)qn.w;
       if (qf & DI_NB) {
-        const uint2 qn = D.nb[wq];
         qnx[0] = (int)(qn.x & 0xffffu); qny[0] = (int)(qn.x >> 16); qnx[1] = (int)(qn.y & 0xffffu); qny[1] = (int)(qn.y >> 16);
+        qnr[0] = (int)(qn.z & 0xffu); qnr[1] = (int)((qn.z >> 8) & 0xffu);
         q_nnb = 1;
       }
       const bool q_nb2 = (qf & DI_NB2) != 0;
@@ -1026,7 +1035,12 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
           const bool oh[2] = {(of & DI_HR) != 0, (of & DI_HA) != 0};
           const int ox[2] = {(int)(o.y & 0xffffu), (int)(o.z & 0xffffu)}, oy[2] = {(int)(o.y >> 16), (int)(o.z >> 16)};
           const int oci[2] = {(int)(o.w & 0xffu), (int)((o.w >> 16) & 0xffu)}, ocj[2] = {(int)((o.w >> 8) & 0xffu), (int)(o.w >> 24)};
-          const int lim2 = ((of & (DI_RESC | DI_NBOV)) || q_far) ? far2 : range2;
+          // how far two rectangles can see each other: the alignment term its range, the overlap term as far as the
+          // circumscribed circles meet (radii rounded up, + 1 px for the rounding and the 1e-7 of the circle test), neither
+          // beyond the terms' cut-off
+          const int o_r = or_[ch];
+          auto reach2 = [&](int ra, int rb) { const int t = (ra + rb + 1) * (ra + rb + 1), a2 = c.pr1.maxd2; const int m = t > a2 ? t : a2; return m < range2 ? m : range2; };
+          const int lim2 = ((of & (DI_RESC | DI_NBOV)) || q_far) ? far2 : reach2(o_r, q_r);
           bool bad = oh[0] && (of & 0xffff) == q_ts;
 #pragma unroll
           for (int a = 0; a < 2; ++a)
@@ -1039,9 +1053,9 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
               }
               if (q_nnb > 0) {
                 const int dx0 = ox[a] - qnx[0], dy0 = oy[a] - qny[0];
-                if (dx0 * dx0 + dy0 * dy0 <= range2) bad = true;
+                if (dx0 * dx0 + dy0 * dy0 <= reach2(o_r, qnr[0])) bad = true;
                 const int dx1 = ox[a] - qnx[1], dy1 = oy[a] - qny[1];
-                if (q_nb2 && dx1 * dx1 + dy1 * dy1 <= range2) bad = true;
+                if (q_nb2 && dx1 * dx1 + dy1 * dy1 <= reach2(o_r, qnr[1])) bad = true;
               }
             }
           if (bad) ok_[ch] = false;
@@ -1124,8 +1138,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
 }
 
 // ---- host-side launcher ----------------------------------------------------------------------------
-extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax) {
-  return deep_base_bytes(cap, ncell, cell_cap, rowbase_n, waves) + deep_extra_bytes(nmax, waves);
+extern "C" size_t mpp_deep_lds_bytes(int cap, int ncell, int cell_cap, int rowbase_n, int waves, int nmax, int ext) {
+  return deep_base_bytes(cap, ncell, cell_cap, rowbase_n, waves) + deep_extra_bytes(nmax, waves, ext);
 }
 extern "C" size_t mpp_deep_static_lds_bytes(int waves) {
   return waves >= MPP_LDS_PARAMS_MIN_WAVES ? ((sizeof(DevParams) + 15) & ~(size_t)15) : 0;

@@ -55,9 +55,11 @@ def resolve_schedule(num_samples: int, init_temperature: float, alpha_t, burn_in
     return float(alpha_t), float(target_temperature), total, snaps
 
 
-#: relative speed of ONE chain with 8 / 4 / 2 / 1 speculative waves (profiles/r01_batched_sweep.json, saturated launches:
-#: 322 k / 238 k / 150 k / 96 k proposals/s per chain on 256-px tiles)
-SPEC_SPEED = {8: 1.0, 4: 0.74, 2: 0.47, 1: 0.30}
+#: relative speed of ONE chain with 8 / 4 / 2 / 1 waves in deep rounds (csrc/mpp_deep.hip; the 512-px bench tile: 117 / 131 /
+#: 177 / 218 ms per 100 001 steps, gpurun_out of round 3; one wave per step, round 1: 1.0 / 0.74 / 0.47 / 0.30)
+SPEC_SPEED = {8: 1.0, 4: 0.89, 2: 0.66, 1: 0.54}
+#: ... and with one wave per step (the kernels chains with the split / merge kernels run on): profiles/r01_batched_sweep.json
+SPEC_SPEED_WAVE = {8: 1.0, 4: 0.74, 2: 0.47, 1: 0.30}
 LDS_PER_CU, WAVES_PER_CU, N_CU = 160 * 1024, 8, 256      # MI355X; 8 waves of 256 VGPRs fill a CU
 
 
@@ -71,7 +73,7 @@ def choose_spec_waves(ctx: MppContext, n_tiles: int, use_split_merge: bool = Fal
         ctx.set_option("spec_waves", spec)
         lds = max(1, ctx.get_option("lds_bytes"))
         resident = N_CU * max(1, min(LDS_PER_CU // lds, WAVES_PER_CU // spec))
-        t = -(-n_tiles // resident) / SPEC_SPEED[spec]
+        t = -(-n_tiles // resident) / (SPEC_SPEED_WAVE if use_split_merge else SPEC_SPEED)[spec]
         if best_t is None or t < best_t - 1e-12:
             best, best_t = spec, t
     return best
