@@ -24,9 +24,9 @@ extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int gr
                                       mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats, int ext);
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
                                             double *dE);
-extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int cap, const double *dE, int dist2,
-                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
-                                        int32_t *n_removed);
+extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
+                                        int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                        double *ta, int32_t *n_removed);
 extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
 extern "C" void mpp_launch_delta_vectors(hipStream_t st, const DevParams *P, const TileRef *tiles, int tile,
@@ -257,7 +257,7 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     if (v != 0 && (v < 8 || v > 256 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..256");
     c->deep = (int)v;
   } else if (!strcmp(name, "deep_gain")) {
-    if (v < 8 || v > 64) return fail(c, -1, "deep_gain must be in 8..64 (eighths)");
+    if ((v & 0xff) < 8 || (v & 0xff) > 64 || (v & ~0x1ffll)) return fail(c, -1, "deep_gain must be in 8..64 (eighths; + 256: sorted steps dealt in blocks)");
     c->deep_gain = (int)v;
   } else if (!strcmp(name, "deep_fixed")) {
     if (v < 0 || v > 256) return fail(c, -1, "deep_fixed must be in 0..256");
@@ -833,16 +833,16 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
                 MPP_MERGE_MAX_POINTS);
   const size_t TC = (size_t)T * c->cap;
   double *d_dE = nullptr, *ts = nullptr, *tr = nullptr, *ta = nullptr;
-  int32_t *work = nullptr, *slot_of = nullptr, *tx = nullptr, *ty = nullptr, *d_rem = nullptr;
+  int32_t *work = nullptr, *lst = nullptr, *slot_of = nullptr, *tx = nullptr, *ty = nullptr, *d_rem = nullptr;
   hipError_t e = hipSuccess;
   auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
   A((void **)&d_dE, TC * 8); A((void **)&ts, TC * 8); A((void **)&tr, TC * 8); A((void **)&ta, TC * 8);
-  A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
+  A((void **)&work, TC * 4); A((void **)&lst, TC * 4); A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
   std::vector<int32_t> h_rem(T, 0);
   if (e == hipSuccess && max_n > 0) {
     const int dist2 = (int)floor(distance * distance + 1e-9);
     mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
-    mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, c->cap, d_dE, dist2, work, slot_of, tx, ty, ts, tr, ta, d_rem);
+    mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
     mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream);
@@ -857,7 +857,7 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
       for (int i = 0; i < n_out[t] && i < m; ++i) dE[(size_t)t * cap + i] = h[(size_t)t * m + i];
   }
   if (n_removed) for (int t = 0; t < T; ++t) n_removed[t] = h_rem[t];
-  void *fr[] = {d_dE, ts, tr, ta, slot_of, tx, ty, d_rem};
+  void *fr[] = {d_dE, ts, tr, ta, work, lst, slot_of, tx, ty, d_rem};
   for (void *p : fr) if (p) (void)hipFree(p);
   HIPCHK(c, e);
   return rc;

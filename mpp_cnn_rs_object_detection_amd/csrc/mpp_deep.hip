@@ -691,6 +691,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
                                                                  unsigned long long seed, unsigned int chain0, int trace_tile,
                                                                  mpp_step_out *out, mpp_proposal *props, int nmax,
                                                                  int fixed_depth, int gain8, unsigned long long *stats) {
+  const bool by_type = (gain8 & 0x100) == 0;      // (bit 8 of the gain word: deal the sorted steps in blocks instead -- A/B tests)
+  gain8 &= 0xff;
   constexpr int NCH = DEEP_NMAX_LIMIT / 64;              // chunks of 64 step reports a lane may have to look at
   const DevParams *P = deep_stage_params<(WAVES >= MPP_LDS_PARAMS_MIN_WAVES)>(Pv, WAVE * WAVES);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -854,9 +856,25 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     __syncthreads();                            // (2)
     DPH(2);
 
-    // ---- B: evaluate my step
+    // ---- B: evaluate my step.  Sorted position e of the thread: with eight waves and the eight kernels of the mixture, wave w
+    //      takes the steps of kernel w (it then runs ONE kernel's code, not the tail of one type and the head of the next);
+    //      otherwise -- or should a type have more than 64 steps -- the sorted steps are dealt to the waves in blocks.
+    int es = e;
     mine = act0 && e < lim;
-    myoff = mine ? (int)D.poff[e] : 0;
+    if (WAVES == 8 && by_type) {
+      bool fits = true;
+#pragma unroll
+      for (int k = 0; k < MPP_NKERNEL; ++k) {
+        const int t_k = __builtin_amdgcn_readlane(tot, k);
+        fits = fits && t_k <= WAVE && (k < WAVES || t_k == 0);
+      }
+      if (fits) {
+        const int first_w = __builtin_amdgcn_readlane(excl, c.wave), tot_w = __builtin_amdgcn_readlane(tot, c.wave);
+        mine = c.lane < tot_w;
+        es = first_w + c.lane;
+      }
+    }
+    myoff = mine ? (int)D.poff[es] : 0;
     r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r.tslot = -1; r.tidx = -1;
     if (mine) {
       Tm = D.tring[(int)((done + myoff) & (long long)rmask)];
@@ -864,7 +882,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       int keep = 0;
       MapVals pmv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
       uint32_t w[8];
-      const uint4 wv = D.pw[e];
+      const uint4 wv = D.pw[es];
       w[0] = wv.x; w[1] = wv.y; w[2] = wv.z; w[3] = wv.w;
       const uint64_t s = (uint64_t)(step0 + done + myoff);
       philox4x32_10((uint32_t)s, (uint32_t)(s >> 32), 1u, chain_t, k0, k1, w + 4);

@@ -250,33 +250,61 @@ __device__ __forceinline__ int wave_min_i(int v) {
   for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, WAVE); v = w < v ? w : v; }
   return v;
 }
+// flags[tile][i] = point i has another point within the distance (the others are their own best and never removed: the walk
+// below only visits the flagged ones -- 5 % of the points of a 5 000-point image).  One lane per point.
+__global__ __launch_bounds__(64) void k_has_neighbour(const TileRef *tiles, int cap, int dist2, int32_t *flags) {
+  const int tile = blockIdx.y, i = blockIdx.x * WAVE + threadIdx.x;
+  TileRef t = tiles[tile];
+  const int n = *t.n;
+  if (i >= n) return;
+  const int xi = t.px[i], yi = t.py[i];
+  int f = 0;
+  for (int j = 0; j < n; ++j) {
+    const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+    f |= (j != i && dx * dx + dy * dy <= dist2) ? 1 : 0;
+  }
+  flags[(size_t)tile * cap + i] = f;
+}
+
 // The dedupe walk of distance_merge (data_loaders.py:140-159 as restated in this repo's data_loaders.distance_merge): in
 // index order, every not-yet-removed point keeps, among the not-yet-removed points within `distance` of it (itself
 // included), only the one with the best intensity exp(-dE) -- scores equal to 1e-9 are a tie and the first wins; a
 // non-finite best score: numpy's argmax (a NaN first, else the first infinity).  Then the removals in index order, each
 // moving the last point into the hole (EPointsSet.remove), which fixes the order of the survivors.  One wave per tile.
 // work: [T][cap] (alive flag, then the survivors' original indices); tmp*: [T][cap] copies of the configuration.
-__global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int cap, const double *dE, int dist2, int32_t *work,
-                                                     int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
-                                                     int32_t *n_removed) {
+__global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int cap, const double *dE, int dist2, const int32_t *work,
+                                                     int32_t *lst_all, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                                     double *ta, int32_t *n_removed) {
   const int tile = blockIdx.x, lane = threadIdx.x;
   TileRef t = tiles[tile];
   const int n = *t.n;
   extern __shared__ unsigned char alive[];                     // [cap] flags (LDS: read in every inner loop)
   int32_t *sl = slot_of + (size_t)tile * cap;
   const double *d = dE + (size_t)tile * cap;
-  (void)work;
-  for (int j = lane; j < n; j += WAVE) alive[j] = 1;
+  const int32_t *flags = work + (size_t)tile * cap;
+  int32_t *lst = lst_all + (size_t)tile * cap;                 // the points that have a neighbour, ascending
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int nl = 0;
+  for (int b = 0; b < n; b += WAVE) {
+    const int j = b + lane;
+    if (j < n) alive[j] = 1;
+    const bool f = j < n && flags[j] != 0;
+    const unsigned long long m = __ballot(f);
+    if (f) lst[nl + __popcll(m & below)] = j;
+    nl += __popcll(m);
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  for (int i = 0; i < n; ++i) {
+  for (int li = 0; li < nl; ++li) {
+    const int i = lst[li];
     if (!alive[i]) continue;                                   // (uniform: every lane reads the same flag)
     const int xi = t.px[i], yi = t.py[i];
     // best score among the alive points within the distance (i itself is one of them)
     double top = -INFINITY;
     int first_nan = 0x7fffffff, cnt = 0;
-    for (int j = lane; j < n; j += WAVE) {
+    for (int lj = lane; lj < nl; lj += WAVE) {
+      const int j = lst[lj];
       const int dx = t.px[j] - xi, dy = t.py[j] - yi;
       if (alive[j] && dx * dx + dy * dy <= dist2) {
         const double sc = exp(-d[j]);
@@ -286,7 +314,7 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
       }
     }
     cnt = wave_sum_i(cnt);
-    if (cnt <= 1) continue;                                    // alone: its own best, nothing to remove
+    if (cnt <= 1) continue;                                    // alone by now: its own best, nothing to remove
     top = wave_max_d(top);
     first_nan = wave_min_i(first_nan);
     const bool finite = first_nan == 0x7fffffff && top - top == 0.0;
@@ -294,7 +322,8 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
     int best = 0x7fffffff;
     if (first_nan != 0x7fffffff) best = first_nan;             // numpy.argmax: the first NaN
     else {
-      for (int j = lane; j < n; j += WAVE) {
+      for (int lj = lane; lj < nl; lj += WAVE) {
+        const int j = lst[lj];
         const int dx = t.px[j] - xi, dy = t.py[j] - yi;
         if (alive[j] && dx * dx + dy * dy <= dist2) {
           const double sc = exp(-d[j]);
@@ -303,7 +332,8 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
       }
       best = wave_min_i(best);
     }
-    for (int j = lane; j < n; j += WAVE) {
+    for (int lj = lane; lj < nl; lj += WAVE) {
+      const int j = lst[lj];
       const int dx = t.px[j] - xi, dy = t.py[j] - yi;
       if (j != best && alive[j] && dx * dx + dy * dy <= dist2) alive[j] = 0;
     }
@@ -349,11 +379,13 @@ extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, 
   if (n_tiles <= 0 || max_n <= 0) return;
   hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE);
 }
-extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int cap, const double *dE, int dist2,
-                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr, double *ta,
-                                        int32_t *n_removed) {
+extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
+                                        int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                        double *ta, int32_t *n_removed) {
   if (n_tiles <= 0) return;
-  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), (size_t)cap, st, tiles, cap, dE, dist2, work, slot_of, tx, ty, ts, tr, ta, n_removed);
+  hipLaunchKernelGGL(k_has_neighbour, dim3((max_n + WAVE - 1) / WAVE, n_tiles), dim3(64), 0, st, tiles, cap, dist2, work);
+  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), (size_t)cap, st, tiles, cap, dE, dist2, (const int32_t *)work, lst, slot_of, tx, ty,
+                     ts, tr, ta, n_removed);
 }
 
 // The same walk, but the per-point energy VECTORS (unit terms, then pair reductions) before and after the

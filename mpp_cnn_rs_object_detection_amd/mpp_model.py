@@ -30,8 +30,8 @@ import numpy as np
 from . import distributed as mdist
 from . import energies as E
 from .custom_types import ImageWMaps
-from .data_loaders import (PATCH_SIZE, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps, merge_patches,
-                           merge_score_images, tile_anchors)
+from .data_loaders import (PATCH_SIZE, Detections, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps,
+                           merge_patches, merge_score_images, tile_anchors)
 from .hip_api import MppError
 from .point_set import EPointsSet
 from .dota_results import DOTAResultsTranslator
@@ -334,9 +334,24 @@ class MPPModel:
             local_error = e
             sampler = None
         # what a caller may want to look at afterwards (tests compare single tiles with the CPU oracle)
+        arrays = sampler is not None and getattr(sampler, "arrays", False)
+        raw = results
+        if arrays:
+            results = [Detections(*r) for r in raw]            # (arrays that read like lists of Rectangle)
         self.last_run = {"seed": seed, "anchors": anchors, "patch": patch, "mine": mine, "tile_results": results,
                          "total_steps": total, "snapshot_step": snaps[-1] if snaps else total - 1,
                          "kernel_ms": sampler.kernel_ms if sampler else 0.0}
+        if world_size == 1 and arrays:
+            # merge + scores on the device (``mpp_merge_score``); an image with more detections than its walk takes: the host
+            xy = [r[0] + np.asarray(t.crop_data["tl_anchor"], dtype=np.int32) for r, t in zip(raw, tiles)]
+            agg = (np.concatenate(xy) if xy else np.zeros((0, 2), np.int32),
+                   np.concatenate([r[1] for r in raw]) if raw else np.zeros((0, 3)))
+            try:
+                return merge_score_images([region_data], [agg], self.energy_model, self.energy_setup, 3, device=self.device)[0]
+            except MppError as e:
+                if e.code != -4:
+                    raise
+            results = [list(r) for r in results]
         if world_size == 1:
             logging.info(f"merging {n_tiles} patches ...")
             merged = merge_patches(patches=tiles, results=results, original_image=region_data, method="distance",
@@ -413,7 +428,11 @@ class MPPModel:
         if world_size > 1:
             def pack(ctx):
                 ctx.pack_detections(mine, np.array([anchors[i] for i in mine]), capacity, buf)
-        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0], on_device=pack)
+        # one rank: the configurations stay arrays when merge + scores run on the device (no picture-reading energy)
+        sampler.arrays = (world_size == 1 and E.classic_image(sampler.model_units) is None
+                          and not self.config["inference"].get("host_merge", False))
+        out = sampler.run(total, snaps, 1, p["init_temperature"], alpha, T_target, seed, chain0=mine[0], on_device=pack,
+                          as_arrays=sampler.arrays)
         sampler.tile_results = [res[-1] if res else [] for res in out]
         self.last_intensity = sampler.intensity
         logging.info(f"ran {len(mine)} rjmcmc chains of {total} steps in one launch in "

@@ -44,7 +44,7 @@ for p in glob.glob("$OUT/pmc*/*/*_counter_collection.csv"):
         if r["Dispatch_Id"] in ids:
             agg[r["Kernel_Name"][:90]][r["Counter_Name"]] += float(r["Counter_Value"])
 out += ["## counters, summed over the same forwards, for the kernels above", "",
-        "| kernel | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | MFMA busy / (4 SIMDs x SQ busy) | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM GB/s (2 x FETCH + WRITE over the kernel's time) |", "|---|---|---|---|---|---|---|"]
+        "| kernel | SQ_VALU_MFMA_BUSY_CYCLES | SQ_BUSY_CYCLES | MFMA busy cycles per SQ busy cycle / 4 | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM GB/s (2 x FETCH + WRITE over the kernel's time) |", "|---|---|---|---|---|---|---|"]
 for k, v in sorted(dur.items(), key=lambda kv: -kv[1])[:25]:
     a = agg.get(k, {})
     mf, sq, fe, wr = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), a.get("SQ_BUSY_CYCLES", 0), a.get("FETCH_SIZE", 0), a.get("WRITE_SIZE", 0)
