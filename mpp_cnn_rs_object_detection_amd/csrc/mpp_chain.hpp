@@ -1238,6 +1238,9 @@ __device__ __forceinline__ void draw_birth(const Chain &c, const uint32_t w[8], 
     TabRows tr{0.0, 0.0};
     if (pre) tr = tab_rows_request(c, ((size_t)row * c.h.W + col) * MPP_NCLASS);
     if (LANE) {
+      // (one row after the other: requesting the three rows together, or searching the cumulative tables with 23 probes
+      // per level instead of 7, costs more in registers -- 143 spills instead of 106 -- than the two or three memory
+      // latencies it saves: 71.8 and 74.9 ms against 67.6 on the config-2 tile, round 3)
 #pragma clang loop unroll(disable)
       for (int k = 0; k < 3; ++k) {
         int cls;
