@@ -272,6 +272,14 @@ int mpp_nhwc_glue(mpp_ctx *ctx, const void *x0, const void *x1, void *y, int H, 
 int mpp_conv3x3_c32(mpp_ctx *ctx, const float *x0, const float *x1, int H, int W, const float *wp, const float *in_scale,
                     const float *in_shift, const float *out_scale, const float *out_shift, int relu, float *y);
 
+/* ShapeNet's three 1x1 heads, their biases and the softmax in one pass (model_parts/shape_net.py:12-46,
+ * shape_net_model.py's inference softmax): h [ldh][ldw][32] float32 channels-last (the backbone's output) ->
+ * marks_* [H][W][32] = softmax_c(sum_i w[k][c][i] * h[i] + b[k][c]), k = size, ratio, angle; w [3][32 classes][32 in],
+ * b [3][32].  Replaces three library convolutions + bias adds + mpp_shapenet_epilogue_nhwc (same values up to float32
+ * summation order).  All device pointers, 16-byte aligned; the ctx's stream. */
+int mpp_shapenet_heads(mpp_ctx *ctx, int H, int W, int ldh, int ldw, const float *h, const float *w, const float *b,
+                       float *marks_size, float *marks_ratio, float *marks_angle);
+
 /* IoU matrix of convex quadrilaterals for the DOTA task-1 evaluation: a [n][8], b [m][8] (x1 y1 .. x4 y4, either
  * orientation) -> out [n][m] = |A_i n B_j| / (|A_i| + |B_j| - |A_i n B_j|), or -1 where the axis-aligned extents
  * (inclusive-pixel +1 convention) do not overlap.  Stands in for `polyiou.iou_poly` and the hbb pre-filter of

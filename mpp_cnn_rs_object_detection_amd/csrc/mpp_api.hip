@@ -47,6 +47,8 @@ extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *
 extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const float *x1, int H, int W, const float *wp,
                                       const float *in_scale, const float *in_shift, const float *out_scale, const float *out_shift,
                                       int relu, float *y);
+extern "C" int mpp_launch_shapenet_heads(hipStream_t st, const float *h, int H, int W, int ldw, const float *wh, const float *bh,
+                                         float *m0, float *m1, float *m2);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
 extern "C" void mpp_launch_pack_detections(hipStream_t st, const TileRef *tiles, int n_tiles, const int32_t *tile_ids,
                                            const int32_t *anchors, int capacity, double *out);
@@ -169,7 +171,7 @@ static const char *chain_error_text(int e) {
 }
 
 // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections; 5: mpp_set_chain_keys, options auto_grow / remap_table
-extern "C" int mpp_abi_version(void) { return 7; }
+extern "C" int mpp_abi_version(void) { return 8; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -1181,6 +1183,18 @@ extern "C" int mpp_conv3x3_c32(mpp_ctx *c, const float *x0, const float *x1, int
   HIPCHK(c, hipSetDevice(c->device));
   if (mpp_launch_conv3x3_c32(c->stream, x0, x1, H, W, wp, in_scale, in_shift, out_scale, out_shift, relu, y))
     return fail(c, -2, "conv3x3_c32 launch failed: %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
+
+extern "C" int mpp_shapenet_heads(mpp_ctx *c, int H, int W, int ldh, int ldw, const float *h, const float *w, const float *b,
+                                  float *marks_size, float *marks_ratio, float *marks_angle) {
+  if (!c || !h || !w || !b || !marks_size || !marks_ratio || !marks_angle || H < 1 || W < 1 || ldh < H || ldw < W)
+    return fail(c, -1, "bad shapenet_heads arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int rc = mpp_launch_shapenet_heads(c->stream, h, H, W, ldw, w, b, marks_size, marks_ratio, marks_angle);
+  if (rc == -2 && (((uintptr_t)h | (uintptr_t)marks_size | (uintptr_t)marks_ratio | (uintptr_t)marks_angle) & 15))
+    return fail(c, -1, "shapenet_heads: the activations and the mark maps must be 16-byte aligned");
+  if (rc) return fail(c, -2, "shapenet_heads launch failed: %s", hipGetErrorString(hipGetLastError()));
   return 0;
 }
 

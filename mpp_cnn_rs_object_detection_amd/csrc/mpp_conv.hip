@@ -59,21 +59,41 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32(const float *__restrict_
   if (n_stage <= 0) return;
 
   float4 pre[CV_LD];
-  // the loads of stage `st` (tile t_begin + st / n_src, source st % n_src) into registers
-#define CV_ISSUE(st_)                                                                                                  \
+  // where in the tile the u-th float4 of this thread lands never changes: (row << 8 | column) of its pixel, worked out once
+  int pp[CV_LD];
+#pragma unroll
+  for (int u = 0; u < CV_LD; ++u) {
+    const int pix = (tid + 256 * u) >> 3, pr = pix / CV_TW;
+    pp[u] = (pr << 8) | (pix - pr * CV_TW);
+  }
+  const int j4 = 4 * (tid & 7);
+  // the u-th load of a stage whose tile starts at (rb + 1, cb + 1) from source xs (already offset by j4)
+#define CV_ISSUE1(u_, xs_, rb_, cb_)                                                                                    \
   do {                                                                                                                  \
-    const int t_ = t_begin + (st_) / n_src, ty_ = t_ / tiles_x, tx_ = t_ - ty_ * tiles_x;                               \
-    const float *x_ = ((st_) % n_src) == 0 ? x0 : x1;                                                                   \
-    _Pragma("unroll") for (int u = 0; u < CV_LD; ++u) {                                                                 \
-      const int q = tid + 256 * u, pix = q >> 3, j = q & 7;                                                             \
-      const int pr = pix / CV_TW, pc = pix - pr * CV_TW;                                                                \
-      const int gr = reflect_idx(min(ty_ * CV_ROWS - 1 + pr, H), H), gc = reflect_idx(min(tx_ * CV_COLS - 1 + pc, W), W); \
-      if (q < CV_TH * CV_TW * 8) pre[u] = *(const float4 *)(x_ + ((size_t)gr * W + gc) * 32 + 4 * j);                   \
-    }                                                                                                                   \
+    const int gr = reflect_idx(min((rb_) + (pp[u_] >> 8), H), H), gc = reflect_idx(min((cb_) + (pp[u_] & 255), W), W);  \
+    if (tid + 256 * (u_) < CV_TH * CV_TW * 8) pre[u_] = *(const float4 *)((xs_) + ((size_t)gr * W + gc) * 32);          \
   } while (0)
-  CV_ISSUE(0);
+  {
+    const int ty_ = t_begin / tiles_x, tx_ = t_begin - ty_ * tiles_x;
+#pragma unroll
+    for (int u = 0; u < CV_LD; ++u) CV_ISSUE1(u, x0 + j4, ty_ * CV_ROWS - 1, tx_ * CV_COLS - 1);
+  }
 
+  const int m = lane & 31, kh = lane >> 5;
+  const float o_sc = out_scale ? out_scale[m] : 1.f, o_sh = out_shift ? out_shift[m] : 0.f;
   f32x16 acc[4];
+  // a finished tile's outputs wait here (scaled, shifted, clamped) and are stored one value per "unit" of the NEXT stage's
+  // MFMA loop: the stores, like the loads of the stage after, are issued while the matrix cores work, and the barrier at
+  // the top of a stage (s_waitcnt vmcnt(0): on gfx9 stores count too) finds them long done
+  float outv[64];
+  bool pend = false;
+  float *pend_y = nullptr;                 // &y[row r0 + 2 * wave][column c0 + 4 * kh][channel m] of the waiting tile
+  int pend_r = 0, pend_c = 0;              // its first row and column (bounds of the image's last tiles)
+#define CV_STORE1(q_)                                                                                                   \
+  do {                                                                                                                  \
+    const int b_ = (q_) >> 4, i_ = (q_) & 15, dr_ = b_ >> 1, dc_ = 32 * (b_ & 1) + (i_ & 3) + 8 * (i_ >> 2);            \
+    if (pend_r + dr_ < H && pend_c + dc_ < W) pend_y[((size_t)dr_ * W + dc_) * 32] = outv[q_];                          \
+  } while (0)
   for (int st = 0; st < n_stage; ++st) {
     const int src = st % n_src, t = t_begin + st / n_src;
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
@@ -88,54 +108,77 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_c32(const float *__restrict_
     const bool aff = src == 0 && in_scale != nullptr;
 #pragma unroll
     for (int u = 0; u < CV_LD; ++u) {
-      const int q = tid + 256 * u, pix = q >> 3, j = q & 7;
+      const int q = tid + 256 * u, pix = q >> 3;
       if (q < CV_TH * CV_TW * 8) {
         float4 v = pre[u];
         if (aff) {
-          const float4 sc = *(const float4 *)(in_scale + 4 * j), sh = *(const float4 *)(in_shift + 4 * j);
+          const float4 sc = *(const float4 *)(in_scale + j4), sh = *(const float4 *)(in_shift + j4);
           v.x = fmaxf(0.f, v.x * sc.x + sh.x); v.y = fmaxf(0.f, v.y * sc.y + sh.y);
           v.z = fmaxf(0.f, v.z * sc.z + sh.z); v.w = fmaxf(0.f, v.w * sc.w + sh.w);
         }
-        float *d = tile + pix * CV_PIX + 4 * j;
+        float *d = tile + pix * CV_PIX + j4;
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       }
     }
     __syncthreads();
-    if (st + 1 < n_stage) CV_ISSUE(st + 1);                   // in flight while the MFMAs below run
-    // ---- 9 taps x 16 channel pairs: one B fragment, four A fragments, four MFMAs
-    const int m = lane & 31, kh = lane >> 5;
+    // the next stage: its source and the corner of its tile
+    const bool has_next = st + 1 < n_stage;
+    const int tn = t_begin + (st + 1) / n_src, tyn = tn / tiles_x, txn = tn - tyn * tiles_x;
+    const float *xn = (((st + 1) % n_src) == 0 ? x0 : x1) + j4;
+    const int rbn = tyn * CV_ROWS - 1, cbn = txn * CV_COLS - 1;
+    // ---- 9 taps x 16 channel pairs: one B fragment, four A fragments, four MFMAs.  A "unit" = one tap, four channels
+    // (two channel pairs): 2 B + 8 A values, 8 MFMAs = 512 matrix-core cycles.  The fragments of unit u + 1 are requested
+    // BEFORE the MFMAs of unit u are issued (two register sets), so that with one wave per SIMD an LDS read has a whole
+    // unit to arrive in.  Between the two halves of a unit's MFMAs goes one load of the next stage (address arithmetic
+    // and all), after them one store of the previous tile: vector work that runs while the matrix cores are busy.
     const float *arow = tile + ((2 * wave) * CV_TW + m) * CV_PIX + kh;       // block b: row 2*wave + (b >> 1), columns 32*(b & 1) + m
     const float *bw = wl + src * CV_W_FLOATS + kh * 32 + m;
+    float fa[2][4][2], fb[2][2];
+#define CV_LOADU(buf_, u_)                                                                                              \
+  do {                                                                                                                  \
+    const int tap_ = (u_) / 8, cq_ = (u_) % 8, dy_ = tap_ / 3, dx_ = tap_ % 3;                                          \
+    _Pragma("unroll") for (int e = 0; e < 2; ++e) fb[buf_][e] = bw[(tap_ * 32 + 4 * cq_ + 2 * e) * 32];                 \
+    _Pragma("unroll") for (int b = 0; b < 4; ++b)                                                                       \
+      _Pragma("unroll") for (int e = 0; e < 2; ++e)                                                                     \
+        fa[buf_][b][e] = arow[(((b >> 1) + dy_) * CV_TW + 32 * (b & 1) + dx_) * CV_PIX + 4 * cq_ + 2 * e];              \
+  } while (0)
+    CV_LOADU(0, 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      const int dy = tap / 3, dx = tap % 3;
+    for (int u = 0; u < 72; ++u) {
+      if (u + 1 < 72) CV_LOADU((u + 1) & 1, u + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < 32; c += 2) {
-        const float bf = bw[(tap * 32 + c) * 32];
+      for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][b][0], fb[u & 1][0], acc[b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u % 3 == 0 && u / 3 < CV_LD && has_next) CV_ISSUE1(u / 3, xn, rbn, cbn);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const float af = arow[(((b >> 1) + dy) * CV_TW + 32 * (b & 1) + dx) * CV_PIX + c];
-          acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[b], 0, 0, 0);
-        }
-      }
+      for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u & 1][b][1], fb[u & 1][1], acc[b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u < 64 && pend) CV_STORE1(u);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef CV_LOADU
+    pend = false;
     if (src + 1 < n_src) continue;
     // ---- epilogue: C/D layout col = lane & 31 (output channel), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (pixel)
-    const int n = lane & 31;
-    const float sc = out_scale ? out_scale[n] : 1.f, sh = out_shift ? out_shift[n] : 0.f;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int row = r0 + 2 * wave + (b >> 1);
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int col = c0 + 32 * (b & 1) + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        float v = acc[b][i] * sc + sh;
-        if (relu) v = fmaxf(0.f, v);
-        if (row < H && col < W) y[((size_t)row * W + col) * 32 + n] = v;
+        float v = acc[b][i] * o_sc + o_sh;
+        outv[16 * b + i] = relu ? fmaxf(0.f, v) : v;
       }
-    }
+    pend = true;
+    pend_r = r0 + 2 * wave; pend_c = c0 + 4 * kh;
+    pend_y = y + ((size_t)pend_r * W + pend_c) * 32 + m;
   }
-#undef CV_ISSUE
+  if (pend) {
+#pragma unroll
+    for (int q = 0; q < 64; ++q) CV_STORE1(q);
+  }
+#undef CV_STORE1
+#undef CV_ISSUE1
 }
 
 extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const float *x1, int H, int W, const float *wp,
@@ -157,5 +200,94 @@ extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const flo
   if (grid < 8) grid = 8;
   hipLaunchKernelGGL(k_conv3x3_c32, dim3(grid), dim3(256), lds, st, x0, x1, H, W, wp, in_scale, in_shift, out_scale, out_shift, relu, y,
                      tiles_x, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+
+// ---- ShapeNet's three 1x1 heads + bias + softmax in one pass (model_parts/shape_net.py:12-46: three Conv2d(32, 32, 1x1);
+// the softmax of shape_net_model.py's inference) ----------------------------------------------------------------------
+// h [ldh][ldw][32] float32 (the backbone's last activation, channels-last) -> marks[k] [H][W][32] for k = size, ratio, angle.
+// Separately (library 1x1 convolution, its bias add, the softmax epilogue) the three heads move 38 GB on a 4096 x 4096
+// image; fused they read h once and write the three mark maps: 8.6 GB.
+// A wave takes 32 consecutive pixels of an image row: their 32 x 32 activations go through LDS (pixel stride 33, as above)
+// into B fragments; A fragments are the head's weights (kept in registers); D[class][pixel] puts 16 classes of one pixel
+// in a lane and the other 16 in lane ^ 32, so the softmax is 16 in-lane steps and one exchange.
+#define HD_PIX 33
+__global__ __launch_bounds__(256) void k_shapenet_heads(const float *__restrict__ h, int H, int W, int ldw, const float *__restrict__ wh,
+                                                        const float *__restrict__ bh, float *__restrict__ m0, float *__restrict__ m1,
+                                                        float *__restrict__ m2, int groups_per_row, int n_groups) {
+  __shared__ float tiles[4][32 * HD_PIX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kh = lane >> 5;
+  float *tile = tiles[wave];
+  // weights of the three heads as A fragments: step s covers channels 2s, 2s + 1; this lane: class n, channel 2s + kh
+  float wa[3][16], bias[3][16];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wa[k][s] = wh[(k * 32 + n) * 32 + 2 * s + kh];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[k][r] = bh[k * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh];
+  }
+  const int n_waves = (int)gridDim.x * 4;
+  for (int g = (int)blockIdx.x * 4 + wave; g < n_groups; g += n_waves) {
+    const int gx = g / groups_per_row, gy0 = (g - gx * groups_per_row) * 32;
+    const int nv = min(32, W - gy0);
+    const float *src = h + ((size_t)gx * ldw + gy0) * 32;
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, p = idx >> 3;
+      v[i] = p < nv ? *(const float4 *)(src + (size_t)idx * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i;
+      float *d = tile + (idx >> 3) * HD_PIX + 4 * (idx & 7);
+      d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float bf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) bf[s] = tile[n * HD_PIX + 2 * s + kh];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // (the next group's stores to the tile come after these reads)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = bias[k][r];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k][s], bf[s], acc, 0, 0, 0);
+      float mx = acc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, acc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float e[16], sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { e[r] = expf(acc[r] - mx); sum += e[r]; }
+      sum += __shfl_xor(sum, 32, 64);
+      if (n < nv) {
+        float *dst = (k == 0 ? m0 : (k == 1 ? m1 : m2)) + ((size_t)gx * W + gy0 + n) * 32 + 4 * kh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(float4 *)(dst + 8 * q) = make_float4(e[4 * q] / sum, e[4 * q + 1] / sum, e[4 * q + 2] / sum, e[4 * q + 3] / sum);
+      }
+    }
+  }
+}
+
+extern "C" int mpp_launch_shapenet_heads(hipStream_t st, const float *h, int H, int W, int ldw, const float *wh, const float *bh,
+                                         float *m0, float *m1, float *m2) {
+  if (H < 1 || W < 1 || ldw < W) return -1;
+  if (((uintptr_t)h & 15) || ((uintptr_t)m0 & 15) || ((uintptr_t)m1 & 15) || ((uintptr_t)m2 & 15)) return -2;
+  const int gpr = (W + 31) / 32;
+  const long long n_groups = (long long)gpr * H;
+  if (n_groups > 0x7fffffffLL) return -1;
+  int grid = (int)((n_groups + 3) / 4);
+  if (grid > 2048) grid = 2048;                       // eight workgroups per CU, each wave strides over the groups
+  hipLaunchKernelGGL(k_shapenet_heads, dim3(grid), dim3(256), 0, st, h, H, W, ldw, wh, bh, m0, m1, m2, gpr, (int)n_groups);
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

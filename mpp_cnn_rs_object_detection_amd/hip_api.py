@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_image", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_merge_score", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_conv3x3_c32", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_conv3x3_c32", "mpp_shapenet_heads", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library(path: Optional[str] = None):
         "mpp_delta_vectors": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp]),
         "mpp_papangelou": (i32, [vp, i32, vp]),
         "mpp_conv3x3_c32": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+        "mpp_shapenet_heads": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
         "mpp_merge_score": (i32, [vp, C.c_double, i32, vp, vp, vp, vp, vp]),
         "mpp_naive_init": (i32, [vp, dbl, dbl]),
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
@@ -537,6 +538,18 @@ class MppContext:
         self._check(self._L.mpp_conv3x3_c32(self._h, _ptr(x0), _ptr(x1), h, w, _ptr(wp), _ptr(in_scale), _ptr(in_shift),
                                             _ptr(out_scale), _ptr(out_shift), 1 if relu else 0, _ptr(out)))
         return out
+
+    def shapenet_heads(self, h, w, b, H: int, W: int, marks):
+        """ShapeNet's three 1x1 heads + biases + softmax in one pass (``mpp_shapenet_heads``): h [1,32,ldh,ldw] float32
+        channels_last, w [3,32,32] (head, class, input channel), b [3,32]; marks: three [H,W,32] float32 CUDA tensors."""
+        import torch
+        ldh, ldw, c = nhwc_shape(h)
+        if c != 32 or h.dtype != torch.float32 or tuple(w.shape) != (3, 32, 32) or tuple(b.shape) != (3, 32) or len(marks) != 3:
+            raise ValueError("shapenet_heads: float32 channels-last activations of 32 channels, w [3,32,32], b [3,32]")
+        if not (w.is_contiguous() and b.is_contiguous() and all(m.is_contiguous() and tuple(m.shape) == (H, W, 32) for m in marks)):
+            raise ValueError("shapenet_heads: contiguous weights and [H,W,32] mark maps")
+        self._check(self._L.mpp_shapenet_heads(self._h, H, W, ldh, ldw, _ptr(h), _ptr(w), _ptr(b), _ptr(marks[0]), _ptr(marks[1]),
+                                               _ptr(marks[2])))
 
     # -- evaluation --------------------------------------------------------------------------------
     def quad_iou(self, a, b) -> np.ndarray:

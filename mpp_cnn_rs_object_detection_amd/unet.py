@@ -254,9 +254,40 @@ class ScoreMapNets:
             self._fold_cache[key] = (w.permute(2, 3, 1, 0).reshape(9, cin // 32, 32, 32).permute(1, 0, 2, 3).contiguous(),)
         return self._fold_cache[key][0]
 
-    def _double_conv_nhwc(self, dc: DoubleConv, x0: Tensor, x1: Optional[Tensor] = None, pool: bool = False) -> Tensor:
+    def _packed_heads(self):
+        """ShapeNet's heads as one [3,32,32] weight block and one [3,32] bias block for ``mpp_shapenet_heads`` (None unless
+        the heads are the reference's three Conv2d(32, 32, 1x1) and the MFMA kernels are on)."""
+        key = (id(self.shp), "heads")
+        if key not in self._fold_cache:
+            convs = [fl[0] for fl in self.shp.final_layers]
+            ok = (self.mfma_conv and len(convs) == 3 and all(isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.in_channels == 32
+                                                              and c.out_channels == 32 and len(fl) == 1
+                                                              for c, fl in zip(convs, self.shp.final_layers)))
+            if ok:
+                w = torch.stack([c.weight.detach().float().reshape(32, 32) for c in convs]).contiguous()
+                b = torch.stack([c.bias.detach().float() if c.bias is not None else torch.zeros(32, device=w.device) for c in convs]).contiguous()
+                self._fold_cache[key] = (w, b)
+            else:
+                self._fold_cache[key] = None
+        return self._fold_cache[key]
+
+    def _folded_after_bias(self, conv: nn.Conv2d, bn: nn.BatchNorm2d, x1_bias: Tensor):
+        """Scale / shift of ``conv`` + ``bn`` when the LAST len(x1_bias) input channels arrive without the per-channel
+        constant ``x1_bias`` their producer (a ConvTranspose2d) should have added: a constant image stays constant under
+        reflect padding, so the convolution of that constant is the per-output constant sum_{c,taps} w[o][c][tap] * b[c],
+        which goes into the shift -- one whole read + write pass over the upsampled activations less per Up block."""
+        key = (id(conv), id(bn), "after_bias")
+        if key not in self._fold_cache:
+            scale, shift = self._folded(conv, bn)
+            w = conv.weight.detach().float()
+            const = (w[:, w.shape[1] - x1_bias.numel():].sum(dim=(2, 3)) @ x1_bias.float())
+            self._fold_cache[key] = (scale, (shift + scale * const).contiguous())
+        return self._fold_cache[key]
+
+    def _double_conv_nhwc(self, dc: DoubleConv, x0: Tensor, x1: Optional[Tensor] = None, pool: bool = False,
+                          x1_bias: Optional[Tensor] = None) -> Tensor:
         seq = dc.double_conv
-        s1, t1 = self._folded(seq[0], seq[1])
+        s1, t1 = self._folded(seq[0], seq[1]) if x1_bias is None else self._folded_after_bias(seq[0], seq[1], x1_bias)
         s2, t2 = self._folded(seq[3], seq[4])
         # The 32-channel, full-resolution level in float32: the hand-written MFMA convolution (csrc/mpp_conv.hip) takes the
         # unpadded activations (reflect padding is index arithmetic), the concat as a second source, the producer's
@@ -283,7 +314,8 @@ class ScoreMapNets:
             skips.append(x)
         for up, skip in zip(net.ascending_path, skips[::-1][1:]):
             w, b = self._weights(up.up)
-            x = self._double_conv_nhwc(up.conv, skip, self._cl(F.conv_transpose2d(x, w, b, stride=2)))
+            # (the transposed convolution's bias is folded into the next convolution's shift: _folded_after_bias)
+            x = self._double_conv_nhwc(up.conv, skip, self._cl(F.conv_transpose2d(x, w, None, stride=2)), x1_bias=b)
         return x
 
     def _head(self, conv: nn.Conv2d, h: Tensor) -> Tensor:
@@ -313,10 +345,18 @@ class ScoreMapNets:
             xi = padded.permute(1, 2, 0).contiguous().unsqueeze(0).permute(0, 3, 1, 2)      # [1,3,H,W] over NHWC memory
             pos_out = self._cl(self._head(self.pos.final_layer, self._backbone_nhwc(self.pos.backbone, xi)))
             h = self._backbone_nhwc(self.shp.backbone, xi)
-            logits = [self._cl(self._head(fl[0], h)) for fl in self.shp.final_layers]
             det = torch.empty((H, W), dtype=torch.float32, device=self.device)
             marks = [torch.empty((H, W, 32), dtype=torch.float32, device=self.device) for _ in range(3)]
             self.ctx.posnet_epilogue_nhwc(pos_out, H, W, self.div_w, self.div_b, det)
+            heads = self._packed_heads()
+            if heads is not None and h.dtype == torch.float32:
+                # the three 1x1 heads, their biases and the softmax in ONE pass over h (csrc/mpp_conv.hip): 8.6 GB of
+                # traffic on a 4096 x 4096 image instead of 38 GB
+                h = self._cl(h)
+                self.ctx.shapenet_heads(h, heads[0], heads[1], H, W, marks)
+                self._keep = (pos_out, h)
+                return det, marks
+            logits = [self._cl(self._head(fl[0], h)) for fl in self.shp.final_layers]
             for k in range(3):
                 self.ctx.shapenet_epilogue_nhwc(logits[k], H, W, marks[k])
             self._keep = (pos_out, logits)    # alive until the kernels on this stream have consumed them

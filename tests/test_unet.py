@@ -281,3 +281,31 @@ def test_mfma_conv3x3_c32_equals_the_library_convolution(cin, H, W):
     # no epilogue: the raw convolution
     raw = ctx.conv3x3_c32(x0, wp, x1=x1, relu=False)
     np.testing.assert_allclose(raw.cpu().numpy(), F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w).cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,ldh,ldw", [(64, 128, 64, 128), (37, 75, 48, 80), (5, 31, 16, 32), (130, 33, 144, 48)])
+def test_fused_shapenet_heads_equal_convolutions_and_softmax(H, W, ldh, ldw):
+    """``mpp_shapenet_heads`` (csrc/mpp_conv.hip): the three Conv2d(32, 32, 1x1) heads of shape_net.py:12-46 with their
+    biases and the softmax over the 32 classes in one pass, cropped from the padded activations [ldh][ldw] to [H][W] --
+    against F.conv2d + torch.softmax in float32 (row lengths that are not multiples of the 32-pixel groups included)."""
+    import torch.nn.functional as F
+    from mpp_cnn_rs_object_detection_amd import hip_api
+    torch.manual_seed(H * 1000 + W)
+    dev = torch.device("cuda", 0)
+    ctx = hip_api.MppContext(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    h = (torch.randn((1, 32, ldh, ldw), device=dev) * 2.0).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((3, 32, 32), device=dev) / 3.0
+    b = torch.randn((3, 32), device=dev)
+    marks = [torch.full((H, W, 32), -1.0, device=dev) for _ in range(3)]
+    ctx.shapenet_heads(h, w, b, H, W, marks)
+    torch.cuda.synchronize()
+    for k in range(3):
+        logits = F.conv2d(h, w[k].reshape(32, 32, 1, 1), b[k])[0, :, :H, :W]
+        ref = torch.softmax(logits, dim=0).permute(1, 2, 0)
+        np.testing.assert_allclose(marks[k].cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(marks[k].sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+    with pytest.raises(ValueError):
+        ctx.shapenet_heads(h, w[:2], b, H, W, marks)
+    ctx.close()
