@@ -23,7 +23,7 @@ extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int gr
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
                                       mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats, int ext);
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
-                                            double *dE);
+                                            double *dE, const int32_t *grid_start, const int32_t *grid_items);
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
                                         int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                         double *ta, int32_t *n_removed);
@@ -70,6 +70,7 @@ extern "C" void mpp_launch_shapenet_epilogue(hipStream_t st, const float *logits
                                              float *marks);
 
 #define MPP_LDS_LIMIT (160 * 1024)
+#define MPP_CELL_CAP_MAX 2048    // entries of a 32-px cell of the spatial hash (16-bit counts); what fits the LDS decides
 
 struct mpp_ctx {
   int device = 0;
@@ -162,7 +163,7 @@ static int scratch_grid(mpp_ctx *c, int tile, int n, const int32_t **start, cons
 
 static const char *chain_error_text(int e) {
   switch (e) {
-    case 1: return "a cell of the spatial hash holds more points than cell_capacity (at most 64) allows";
+    case 1: return "a cell of the spatial hash holds more points than cell_capacity allows and a larger one does not fit the LDS";
     case 2: return "point capacity of the tile exceeded (a larger point_capacity does not fit the chain's LDS budget, or auto_grow is off)";
     case 3: return "proposal refers to a point that does not exist or lies outside the tile";
     case 4: return "candidate list overflow (lower cell_capacity or report)";
@@ -279,7 +280,7 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
     if (v < 0) return fail(c, -1, "scratch_grid_min_points must be >= 0");
     c->grid_min_points = (int)v;
   } else if (!strcmp(name, "cell_capacity")) {
-    if (v < 1 || v > 64) return fail(c, -1, "cell_capacity must be in 1..64");
+    if (v < 1 || v > MPP_CELL_CAP_MAX) return fail(c, -1, "cell_capacity must be in 1..%d", MPP_CELL_CAP_MAX);
     c->cell_cap = (int)v; c->params_dirty = true;
   } else if (!strcmp(name, "auto_grow")) {
     c->auto_grow = v ? 1 : 0;
@@ -843,10 +844,23 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
   std::vector<int32_t> h_rem(T, 0);
   if (e == hipSuccess && max_n > 0) {
     const int dist2 = (int)floor(distance * distance + 1e-9);
-    mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
-    mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
-    mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE);
-    e = hipGetLastError();
+    // one image (T == 1, thousands of detections): the from-scratch energies look their neighbours up in the candidate grid
+    // (built on the device, again after the removals), as mpp_papangelou does
+    const int32_t *gs = nullptr, *gi = nullptr;
+    if (T == 1 && scratch_grid(c, 0, max_n, &gs, &gi)) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, gs, gi);
+      mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
+      if (T == 1) {
+        e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && scratch_grid(c, 0, max_n - h_rem[0], &gs, &gi)) e = hipErrorOutOfMemory;
+      }
+    }
+    if (e == hipSuccess) {
+      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, gs, gi);
+      e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   }
@@ -1029,6 +1043,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
            mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_) + mpp_deep_static_lds_bytes(c->spec) > MPP_LDS_LIMIT)
       nmax /= 2;
     if (nmax < c->spec || nmax < 8) nmax = 0;
+    if (c->cell_cap > 64) nmax = 0;        // (the deep kernel lists a cell's candidates in a 64-bit mask: fuller cells run one step per wave)
     if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_);
     else if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
@@ -1059,7 +1074,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     if (!cell && !point) return 0;
     const bool can_grow = c->auto_grow != 0;
     int new_cell = c->cell_cap, new_cap = c->cap;
-    if (cell) new_cell = c->cell_cap * 2 > 64 ? 64 : c->cell_cap * 2;
+    if (cell) new_cell = c->cell_cap * 2 > MPP_CELL_CAP_MAX ? MPP_CELL_CAP_MAX : c->cell_cap * 2;
     if (point) new_cap = c->cap * 2 > 65535 ? 65535 : c->cap * 2;
     if (!can_grow || (cell && new_cell == c->cell_cap) || (point && new_cap == c->cap) ||
         chain_lds_total(c, new_cap, new_cell) > MPP_LDS_LIMIT) {

@@ -1391,10 +1391,13 @@ __device__ void cell_remove(const Chain &c, int cell, int slot) {
   const Lds &L = c.L;
   int cnt = L.cell_cnt[cell];
   unsigned short *it = L.cell_items + (size_t)cell * c.h.cell_cap;
-  unsigned long long m = __ballot(c.lane < cnt && it[c.lane] == slot);
+  int idx = -1;
+  for (int e0 = 0; e0 < cnt && idx < 0; e0 += WAVE) {         // (a cell may hold more entries than a wave has lanes)
+    const unsigned long long m = __ballot(e0 + c.lane < cnt && it[e0 + c.lane] == slot);
+    if (m) idx = e0 + __ffsll((long long)m) - 1;
+  }
   wave_lds_fence();
-  if (m && c.lane == 0) {
-    int idx = __ffsll((long long)m) - 1;
+  if (idx >= 0 && c.lane == 0) {
     it[idx] = it[cnt - 1];
     L.cell_cnt[cell] = (unsigned short)(cnt - 1);
   }

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
 
 // Papangelou of every point: dE[tile][i] = E(with u_i) - E(without u_i), i.e. minus the delta of removing it.  One wave per
 // point, the body of k_delta_batch with the one removal (same lanes, same reduction tree: the values of mpp_papangelou).
-__global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, const TileRef *tiles, int cap, double *dE) {
+// `g`: the candidate grid of tile 0 when the launch has ONE tile (a whole image's thousands of detections: without it every
+// point_energy below scans all of them), else {nullptr, nullptr}.
+__global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, const TileRef *tiles, int cap, double *dE, Grid g) {
   __shared__ double part[64];
   __shared__ int32_t ex;
   const int tile = blockIdx.y, cs = blockIdx.x;
@@ -222,7 +224,6 @@ __global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, con
   __syncthreads();
   Overlay o{1, &ex, 0, nullptr, nullptr};
   Overlay none{0, nullptr, 0, nullptr, nullptr};
-  const Grid g{nullptr, nullptr};
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     Rect u = tile_rect(t, i);
@@ -375,9 +376,10 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
   }
 }
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
-                                            double *dE) {
+                                            double *dE, const int32_t *grid_start, const int32_t *grid_items) {
   if (n_tiles <= 0 || max_n <= 0) return;
-  hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE);
+  const Grid g = n_tiles == 1 ? Grid{grid_start, grid_items} : Grid{nullptr, nullptr};
+  hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE, g);
 }
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
                                         int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,

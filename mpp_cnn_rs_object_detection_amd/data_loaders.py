@@ -209,6 +209,8 @@ def merge_score_images(regions: List[ImageWMaps], aggregated, energy_model, ener
 
     def stack(arrs):
         if all(hasattr(a, "data_ptr") for a in arrs):
+            if len(arrs) == 1 and arrs[0].is_contiguous():
+                return arrs[0].unsqueeze(0)              # (one image: its maps as they are -- 6.5 GB at 4096 x 4096)
             base = arrs[0]._base if hasattr(arrs[0], "_base") else None
             # (views of one batch tensor, in order: borrow it as it is instead of copying 100 B per pixel)
             if base is not None and len(base) == len(arrs) and all(a._base is base and a.data_ptr() == base[k].data_ptr()

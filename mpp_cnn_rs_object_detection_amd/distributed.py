@@ -57,7 +57,20 @@ def init_process_group(backend: str = None):
     if backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # the group this module made is torn down when the interpreter exits: a process that ends with the backend's worker
+    # threads still joinable aborts now and then ("terminate called without an active exception", exit code -6)
+    import atexit
+    atexit.register(_shutdown)
     return rank, world
+
+
+def _shutdown():
+    try:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:              # noqa: BLE001 -- the run itself is over; nothing to report to
+        pass
 
 
 def pack_detections(tile_ids: Sequence[int], points: Sequence[Tuple[np.ndarray, np.ndarray]],

@@ -16,4 +16,4 @@ data = ImageWMaps(name="0001", shape=(size, size), image=None, detection_map=tor
 model.rng = np.random.default_rng(0); model.infer_image(data)
 model.rng = np.random.default_rng(0)
 pr = cProfile.Profile(); pr.enable(); model.infer_image(data); torch.cuda.synchronize(); pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)

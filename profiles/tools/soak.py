@@ -1,7 +1,7 @@
 """Soak of the production chain kernel (8 speculative waves, untraced) against the C oracle: random tile sizes,
 densities, crowding, temperatures, both energy setups, with and without split / merge kernels (tests/helpers.py:
 soak_case); the final configurations must agree (centres exactly, marks to 1e-9).
-`python profiles/tools/soak.py [cases] [first] [sm]` on the GPU box; one line per case and a summary.  A verification run, not
+`[SOAK_CASES=a,b,..] python profiles/tools/soak.py [cases] [first] [sm]` on the GPU box; one line per case and a summary.  A verification run, not
 part of the test suite (~0.6 s per case); the cases it ever caught are regression tests in tests/test_gpu_chain.py."""
 import os
 import sys
@@ -20,7 +20,9 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only_sm = len(sys.argv) > 3 and sys.argv[3] == "sm"      # only the cases with split / merge kernels
 bad, skipped = [], 0
 t0 = time.time()
-for k in range(first, first + n_cases):
+cases = [int(v) for v in os.environ["SOAK_CASES"].split(",")] if os.environ.get("SOAK_CASES") else range(first, first + n_cases)
+n_cases = len(cases)
+for k in cases:                                           # (SOAK_CASES=1100,1188,...: exactly these)
     c = soak_case(k)
     if only_sm and "split/merge=1" not in c["text"]:
         skipped += 1

@@ -358,14 +358,16 @@ def test_short_range_model_parallel_commit_matches_the_oracle():
     assert len(oxy) > 20                                    # still crowded at the end: the rule was exercised
 
 
-@pytest.mark.parametrize("case", [18, 10, 15, 516, 812])
+@pytest.mark.parametrize("case", [18, 10, 15, 516, 812, 524, 34])
 def test_soak_cases_that_once_failed(case):
     """Cases of the oracle soak (profiles/tools/soak.py; tests/helpers.py: soak_case) kept as regression tests.
     18: a merge evaluated speculatively found no neighbour around a point that an earlier step of the same round had
     moved next to one and was committed as an empty step (it must ask for an apply round instead); 516, 812: hot
     chains with split kernels crowd more than 32 points into a merge radius -- the partner used to be picked from a
-    32-entry list (error -14), now beyond 32 neighbours it is ranked without a list; the others are split/merge and
-    crowded cases of the same generator."""
+    32-entry list (error -14), now beyond 32 neighbours it is ranked without a list; 524, 34: hot split / merge chains on a 64-px tile that put more than 64
+    points into one 32-px cell -- the limit of the spatial hash until round 3 (error -11), now the cell capacity grows
+    as far as the LDS allows (such chains run one step per wave); the others are split/merge and crowded cases of the
+    same generator."""
     from helpers import soak_case
     c = soak_case(case)
     t = c["tile"]
