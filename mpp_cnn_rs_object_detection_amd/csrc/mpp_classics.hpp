@@ -10,7 +10,8 @@
 //    which is exactly the parity the crossing test computes pixel by pixel (same float64 expression for the crossing);
 //  * a dilation step is  row | row << 1 | row >> 1 | row above | row below, clipped to the image;
 //  * the statistics walk the set bits in row-major order, two passes (mean, then variance), as numpy does.
-// These are slow-path terms (the reference's classical baseline): no wave cooperation, private arrays.
+// That one-thread form serves the from-scratch kernels and the chain's set-up; the steps of a chain use the
+// wave-cooperative form further down (rows, then columns, across lanes; registers only), which returns the same bits.
 #pragma once
 
 #define MPP_CL_ROWS 96        // bounding box of the largest rectangle the mappings allow (size <= 32) + margins
@@ -61,45 +62,39 @@ __device__ inline int cl_count(const ClGrid &G, const Bits128 *a) {
   for (int i = 0; i < G.nr; ++i) n += __popcll(a[i].lo) + __popcll(a[i].hi);
   return n;
 }
-// Sums over the pixels of a mask, row-major, for up to three channels at once: out[ch] = sum x (mu == nullptr) or
-// sum (x - mu[ch])^2.  Pixels are taken 16 at a time: their loads (up to 48) are issued together and then added in pixel
-// order -- one memory latency per 16 pixels instead of one per pixel and channel, the same sums bit for bit.
-#define MPP_CL_BATCH 16
-__device__ inline void cl_flush(const size_t *off, int nb, const MPP_GLOBAL float *img, int C, const double *mu, double *acc) {
-  float v[MPP_CL_BATCH][3];
-#pragma unroll
-  for (int k = 0; k < MPP_CL_BATCH; ++k) {
-    const size_t o = off[k < nb ? k : 0] * (size_t)C;          // (slots beyond nb re-read pixel 0 and are ignored)
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) v[k][ch] = img[o + (ch < C ? ch : 0)];
-  }
-#pragma unroll
-  for (int k = 0; k < MPP_CL_BATCH; ++k)
-    if (k < nb) {
-#pragma unroll
-      for (int ch = 0; ch < 3; ++ch) {
-        const double x = (double)v[k][ch];
-        if (mu) { const double d = x - mu[ch]; acc[ch] += d * d; } else acc[ch] += x;
-      }
-    }
-}
+// Sums over the pixels of a mask for up to three channels: out[ch] = sum x (mu == nullptr) or sum (x - mu[ch])^2.  The ORDER of
+// the additions is the one the wave-cooperative form below can reproduce with one lane per column: every column adds its
+// pixels from the first row to the last, column j and column j + 64 are added, and the 64 values are combined by the
+// butterfly of a wave reduction (partner lane ^ 32, ^ 16, ... ^ 1) -- so a value computed by one thread here (from-scratch
+// kernels, the chain's set-up) and by a wave there (the chain's steps) is the same bit pattern.  The reference adds in
+// row-major order (numpy, two passes); the results agree to a few 1e-16 relative (tests: 1e-12).
 __device__ inline int cl_sums(const ClGrid &G, const Bits128 *m, const MPP_GLOBAL float *img, int W, int C, const double *mu,
                               double *acc) {
-  size_t off[MPP_CL_BATCH];
-  int nb = 0, n = 0;
-  acc[0] = acc[1] = acc[2] = 0.0;
-  for (int i = 0; i < G.nr; ++i)
-    for (int h = 0; h < 2; ++h) {
-      unsigned long long w = h ? m[i].hi : m[i].lo;
-      while (w) {
-        const int j = __ffsll((long long)w) - 1 + 64 * h;
-        w &= w - 1;
-        off[nb++] = (size_t)(G.r0 + i) * W + (G.c0 + j);
-        ++n;
-        if (nb == MPP_CL_BATCH) { cl_flush(off, nb, img, C, mu, acc); nb = 0; }
+  int n = 0;
+  for (int i = 0; i < G.nr; ++i) n += __popcll(m[i].lo) + __popcll(m[i].hi);
+  for (int ch = 0; ch < 3; ++ch) {
+    acc[ch] = 0.0;
+    if (ch >= C) continue;
+    double col[MPP_CL_COLS];
+    for (int j = 0; j < MPP_CL_COLS; ++j) col[j] = 0.0;
+    for (int i = 0; i < G.nr; ++i)
+      for (int h = 0; h < 2; ++h) {
+        unsigned long long w = h ? m[i].hi : m[i].lo;
+        while (w) {
+          const int j = __ffsll((long long)w) - 1 + 64 * h;
+          w &= w - 1;
+          const double x = (double)img[((size_t)(G.r0 + i) * W + (G.c0 + j)) * (size_t)C + ch];
+          if (mu) { const double d = x - mu[ch]; col[j] += d * d; } else col[j] += x;
+        }
       }
+    double t[64], t2[64];
+    for (int l = 0; l < 64; ++l) t[l] = col[l] + col[l + 64];
+    for (int o = 32; o > 0; o >>= 1) {
+      for (int l = 0; l < 64; ++l) t2[l] = t[l] + t[l ^ o];
+      for (int l = 0; l < 64; ++l) t[l] = t2[l];
     }
-  if (nb) cl_flush(off, nb, img, C, mu, acc);
+    acc[ch] = t[0];
+  }
   return n;
 }
 // mean and (population) variance per channel over the pixels of a mask, two passes as numpy does
@@ -197,6 +192,211 @@ __device__ __noinline__ double classic_contrast(const mpp_unit_term &u, const MP
   }
   double mi[3], mo[3], vi[3], vo[3];
   const int ni = cl_stats(G, fill, img, W, C, mi, vi), no = cl_stats(G, a, img, W, C, mo, vo);
+  double val = 0.0;
+  for (int ch = 0; ch < C; ++ch) val += u.p[5] * cl_measure((int)u.p[0], mi[ch], mo[ch], vi[ch], vo[ch], ni, no);
+  return val - u.p[4];
+}
+
+// ---- ContrastEnergy.compute by a whole wave (all 64 lanes, the same rectangle in every lane) ---------------------------------
+// Rows of the grid across lanes -- lane l holds rows l and l + 64 of every mask in registers (no private arrays: the
+// one-thread form above keeps 6 KB of them in scratch memory and a chain's step took 15 us) -- for the fill and the
+// dilations (the rows above and below come from the neighbouring lanes), then COLUMNS across lanes for the statistics:
+// the masks of a row are broadcast, lane l looks at columns l and l + 64 of it (consecutive lanes read consecutive pixels)
+// and adds in the order cl_sums() spells out; the same values bit for bit.
+struct Rows2 { Bits128 a, b; };                       // rows lane and lane + 64
+__device__ __forceinline__ Bits128 b_shfl(Bits128 v, int src) {
+  return Bits128{(unsigned long long)__shfl((long long)v.lo, src, 64), (unsigned long long)__shfl((long long)v.hi, src, 64)};
+}
+__device__ __forceinline__ Bits128 b_readlane(Bits128 v, int src) {          // src wave-uniform
+  const unsigned int x0 = (unsigned int)__builtin_amdgcn_readlane((int)(v.lo & 0xffffffffull), src),
+                     x1 = (unsigned int)__builtin_amdgcn_readlane((int)(v.lo >> 32), src),
+                     x2 = (unsigned int)__builtin_amdgcn_readlane((int)(v.hi & 0xffffffffull), src),
+                     x3 = (unsigned int)__builtin_amdgcn_readlane((int)(v.hi >> 32), src);
+  return Bits128{((unsigned long long)x1 << 32) | x0, ((unsigned long long)x3 << 32) | x2};
+}
+__device__ __forceinline__ int rows_count(const Rows2 &m) {
+  int n = __popcll(m.a.lo) + __popcll(m.a.hi) + __popcll(m.b.lo) + __popcll(m.b.hi);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  return n;
+}
+// utils/morpho.py:9-19, n_iter steps; rows at or beyond G.nr are zero and stay zero, rows outside the image keep their value
+__device__ inline void rows_dilate(const ClGrid &G, int H, Rows2 &m, int n_iter, int lane) {
+  const Bits128 zero{0ull, 0ull};
+  const bool two = G.nr > 64;                          // (wave-uniform)
+  const int row_a = G.r0 + lane, row_b = G.r0 + 64 + lane;
+  const bool upd_a = lane < G.nr && row_a >= 0 && row_a < H, upd_b = 64 + lane < G.nr && row_b >= 0 && row_b < H;
+  for (int it = 0; it < n_iter; ++it) {
+    const Bits128 t = m.a;
+    Bits128 up = b_shfl(t, lane > 0 ? lane - 1 : 0), dn = b_shfl(t, lane < 63 ? lane + 1 : 63);
+    if (lane == 0) up = zero;
+    Bits128 first_b = zero;
+    if (two) first_b = b_readlane(m.b, 0);
+    if (lane == 63) dn = first_b;
+    Bits128 v = b_or(b_or(t, b_or(b_shl1(t), b_shr1(t))), b_or(up, dn));
+    if (two) {
+      const Bits128 tb = m.b, last_a = b_readlane(t, 63);
+      Bits128 upb = b_shfl(tb, lane > 0 ? lane - 1 : 0), dnb = b_shfl(tb, lane < 63 ? lane + 1 : 63);
+      if (lane == 0) upb = last_a;
+      if (lane == 63) dnb = zero;
+      const Bits128 vb = b_or(b_or(tb, b_or(b_shl1(tb), b_shr1(tb))), b_or(upb, dnb));
+      if (upd_b) m.b = b_and(vb, G.cols);
+    }
+    if (upd_a) m.a = b_and(v, G.cols);
+  }
+}
+// 64 x 64 bit transpose across the wave: lane r brings row r (bit c = column c), lane c leaves with column c (bit r = row r)
+__device__ __forceinline__ unsigned long long bit_transpose64(unsigned long long x, int lane) {
+#define MPP_TR_STEP(s_, m_)                                                                                             \
+  {                                                                                                                     \
+    const unsigned long long m = (m_), y = (unsigned long long)__shfl_xor((long long)x, (s_), 64);                       \
+    x = (lane & (s_)) ? (((y >> (s_)) & m) | (x & ~m)) : ((x & m) | ((y << (s_)) & ~m));                                 \
+  }
+  MPP_TR_STEP(32, 0x00000000FFFFFFFFull) MPP_TR_STEP(16, 0x0000FFFF0000FFFFull) MPP_TR_STEP(8, 0x00FF00FF00FF00FFull)
+  MPP_TR_STEP(4, 0x0F0F0F0F0F0F0F0Full) MPP_TR_STEP(2, 0x3333333333333333ull) MPP_TR_STEP(1, 0x5555555555555555ull)
+#undef MPP_TR_STEP
+  return x;
+}
+// a mask by columns: [h][set] = rows 64 * set .. of column 64 * h + lane
+struct Cols4 { unsigned long long w[2][2]; };
+__device__ inline Cols4 rows_to_cols(const Rows2 &m, bool two, bool wide, int lane) {
+  Cols4 o;
+  o.w[0][0] = bit_transpose64(m.a.lo, lane);
+  o.w[0][1] = two ? bit_transpose64(m.b.lo, lane) : 0ull;
+  o.w[1][0] = wide ? bit_transpose64(m.a.hi, lane) : 0ull;
+  o.w[1][1] = (wide && two) ? bit_transpose64(m.b.hi, lane) : 0ull;
+  return o;
+}
+// per-channel sums over two disjoint masks at once (f: the rectangle, r: its rim), lane = column (and column + 64): every
+// lane walks the rows of ITS column from the first to the last -- the masks arrive transposed, so there is nothing to
+// broadcast -- four pixels at a time (their loads are issued together, then added in row order: a wave alone on its SIMD
+// hides no latency).  out[0..2] fill, [3..5] rim; the order of the additions is the one cl_sums() spells out.
+__device__ inline void cols_sums(const ClGrid &G, const Cols4 &f, const Cols4 &r, bool two, bool wide, const MPP_GLOBAL float *img,
+                                 int W, int C, const double *mu_f, const double *mu_r, double *out, int lane) {
+  double acc_f[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}}, acc_r[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && !wide) continue;                                 // (wave-uniform)
+    const MPP_GLOBAL float *colp = img + ((size_t)G.r0 * W + (G.c0 + 64 * h + lane)) * (size_t)C;
+    const size_t row_stride = (size_t)W * (size_t)C;
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+      if (set == 1 && !two) continue;                              // (wave-uniform)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const unsigned int ff = (unsigned int)(half ? f.w[h][set] >> 32 : f.w[h][set]);
+        unsigned int w = ff | (unsigned int)(half ? r.w[h][set] >> 32 : r.w[h][set]);
+        const int base = 64 * set + 32 * half;
+        while (__ballot(w != 0u) != 0ull) {
+          float x[4][3];
+          bool ok[4], isf[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ok[q] = w != 0u;
+            const int b = ok[q] ? __ffs((int)w) - 1 : 0;
+            isf[q] = (ff >> b) & 1u;
+            w &= w - 1u;
+            const MPP_GLOBAL float *px = colp + (size_t)(base + b) * row_stride;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) x[q][ch] = ok[q] ? px[ch < C ? ch : 0] : 0.f;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+              if (ch >= C) continue;
+              double v = (double)x[q][ch];
+              if (mu_f) { const double d = v - (isf[q] ? mu_f[ch] : mu_r[ch]); v = d * d; }
+              if (isf[q]) acc_f[h][ch] += v; else acc_r[h][ch] += v;
+            }
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    double a = acc_f[0][ch] + acc_f[1][ch], b = acc_r[0][ch] + acc_r[1][ch];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a = a + __shfl_xor(a, o, 64); b = b + __shfl_xor(b, o, 64); }
+    out[ch] = a; out[3 + ch] = b;
+  }
+}
+__device__ inline double classic_contrast_wave(const mpp_unit_term &u, const MPP_GLOBAL float *img, int C, int H, int W,
+                                               const Geo &g, int lane) {
+  double r[4], c[4];
+  cl_ref_corners(g, r, c);
+  double rmin = r[0], rmax = r[0], cmin = c[0], cmax = c[0];
+  for (int i = 1; i < 4; ++i) {
+    rmin = r[i] < rmin ? r[i] : rmin; rmax = r[i] > rmax ? r[i] : rmax;
+    cmin = c[i] < cmin ? c[i] : cmin; cmax = c[i] > cmax ? c[i] : cmax;
+  }
+  const int minr = (int)(rmin > 0.0 ? rmin : 0.0), minc = (int)(cmin > 0.0 ? cmin : 0.0);
+  int maxr = (int)ceil(rmax), maxc = (int)ceil(cmax);
+  maxr = maxr > H - 1 ? H - 1 : maxr; maxc = maxc > W - 1 ? W - 1 : maxc;
+  if (maxr < minr || maxc < minc) return u.p[6];
+  const int dil = (int)u.p[1], gap = (int)u.p[2], ero = (int)u.p[3];
+  const int reach = (2 + ero) > (gap + dil) ? (2 + ero) : (gap + dil);
+  const int M = 1 + reach;
+  ClGrid G;
+  G.r0 = minr - M; G.c0 = minc - M; G.nr = maxr - minr + 1 + 2 * M;
+  const int nc = maxc - minc + 1 + 2 * M;
+  if (G.nr > MPP_CL_ROWS || nc > MPP_CL_COLS) return nan("");
+  {
+    const int lo = G.c0 < 0 ? -G.c0 : 0, hi = (W - G.c0) < nc ? (W - G.c0) : nc;
+    G.cols = b_andn(b_prefix(hi), b_prefix(lo));
+  }
+  const Bits128 window = b_andn(b_prefix(maxc - G.c0 + 1), b_prefix(minc - G.c0));
+  const Bits128 zero{0ull, 0ull};
+  auto fill_row = [&](int i) -> Bits128 {
+    const int row = G.r0 + i;
+    Bits128 acc{0ull, 0ull};
+    if (i < G.nr && row >= minr && row <= maxr) {
+      const double y = (double)row;
+      int j = 3;
+      for (int e = 0; e < 4; ++e) {
+        if (((r[e] <= y) && (y < r[j])) || ((r[j] <= y) && (y < r[e]))) {
+          const double xc = (c[j] - c[e]) * (y - r[e]) / (r[j] - r[e]) + c[e];
+          double k = ceil(xc) - (double)G.c0;
+          k = k < 0.0 ? 0.0 : (k > 128.0 ? 128.0 : k);
+          acc = b_xor(acc, b_prefix((int)k));
+        }
+        j = e;
+      }
+      acc = b_and(acc, window);
+    }
+    return acc;
+  };
+  Rows2 fill{fill_row(lane), G.nr > 64 ? fill_row(64 + lane) : zero};
+  if (rows_count(fill) == 0) return u.p[6];
+  Rows2 a;
+  if (ero > 0) {                                   // classics.py:178-182
+    a = fill;
+    rows_dilate(G, H, a, 2, lane);
+    a.a = b_andn(a.a, fill.a); a.b = b_andn(a.b, fill.b);
+    rows_dilate(G, H, a, ero, lane);
+    fill.a = b_andn(fill.a, a.a); fill.b = b_andn(fill.b, a.b);
+    if (rows_count(fill) == 0) return u.p[6];
+  }
+  a = fill;
+  if (gap > 0) {                                   // :187-190
+    rows_dilate(G, H, a, gap, lane);
+    Rows2 rim = a;
+    rows_dilate(G, H, rim, dil, lane);
+    a.a = b_andn(rim.a, a.a); a.b = b_andn(rim.b, a.b);
+  } else {                                         // :191-193
+    rows_dilate(G, H, a, dil, lane);
+    a.a = b_andn(a.a, fill.a); a.b = b_andn(a.b, fill.b);
+  }
+  const int ni = rows_count(fill), no = rows_count(a);
+  double sums[6], mi[3], mo[3], vi[3], vo[3];
+  const bool two = G.nr > 64, wide = nc > 64;                       // (wave-uniform)
+  const Cols4 cf = rows_to_cols(fill, two, wide, lane), cr = rows_to_cols(a, two, wide, lane);
+  cols_sums(G, cf, cr, two, wide, img, W, C, nullptr, nullptr, sums, lane);
+  for (int ch = 0; ch < 3; ++ch) { mi[ch] = sums[ch] / (double)ni; mo[ch] = sums[3 + ch] / (double)no; }
+  cols_sums(G, cf, cr, two, wide, img, W, C, mi, mo, sums, lane);
+  for (int ch = 0; ch < 3; ++ch) { vi[ch] = sums[ch] / (double)ni; vo[ch] = sums[3 + ch] / (double)no; }
   double val = 0.0;
   for (int ch = 0; ch < C; ++ch) val += u.p[5] * cl_measure((int)u.p[0], mi[ch], mo[ch], vi[ch], vo[ch], ni, no);
   return val - u.p[4];

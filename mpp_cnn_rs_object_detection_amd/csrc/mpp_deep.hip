@@ -134,8 +134,29 @@ __device__ __forceinline__ void write_slot_1(const Chain &c, int slot, const Rec
 // evaluate() of mpp_chain.hpp in its lane form, in two halves around the ONE call of eval_delta_lane the kernel has (the
 // step's evaluation and, for a step that commits, the second pass that writes the neighbours' reductions go through the
 // same call site: with two, the inliner leaves a real call behind and the chain state lives in scratch memory)
+// the geometry of the rectangle a step adds (what of it the step keeps from its target comes from the target's cached values)
+__device__ __forceinline__ void deep_add_geo(const Chain &c, Rec &r, int keep) {
+  const Lds &L = c.L;
+  r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
+  if (r.has_add) {
+    Geo g;
+    g.x = r.ax; g.y = r.ay; g.hl = g.hw = g.ca = g.sa = 0.0;
+    double rad = 0.0;
+    if (keep & KEEP_SIZE) { g.hl = L.hl[r.tslot]; g.hw = L.hw[r.tslot]; rad = L.rad[r.tslot]; }
+    else {
+      double length = (2.0 * r.as) / (1.0 + r.ar), width = r.ar * length;
+      g.hl = length / 2.0; g.hw = width / 2.0;
+      rad = geo_radius(g);
+    }
+    if (keep & KEEP_TRIG) { g.ca = L.ca[r.tslot]; g.sa = L.sa[r.tslot]; }
+    else if (keep & KEEP_EDGE_ANGLE) { g.ca = L.trig[r.acls]; g.sa = L.trig[MPP_NCLASS + r.acls]; }
+    else { double al = r.aa + MPP_PI / 2.0; g.ca = cos(al); g.sa = sin(al); }
+    r.hl = g.hl; r.hw = g.hw; r.ca = g.ca; r.sa = g.sa; r.rad = rad;
+  }
+}
+// `contrast_pre`: the ContrastEnergy term of the added rectangle, computed by the whole wave beforehand (or nullptr)
 template <bool EXT>
-__device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool tracing, const MapVals &pmv) {
+__device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool tracing, const MapVals &pmv, const double *contrast_pre) {
   const DevParams *P = c.P;
   const Lds &L = c.L;
   MapVals mv{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
@@ -143,23 +164,11 @@ __device__ __forceinline__ void deep_pre(const Chain &c, Rec &r, int keep, bool 
   else if (r.has_add) mv = load_map_vals_w(P, c.h.W, c.t, L.edges, Rect{r.ax, r.ay, r.as, r.ar, r.aa});
   proposal_densities(c, r, tracing, keep, false);
   r.dE = 0.0; r.n_stash = 0; r.lin_a = 0.0; r.gate_a = 1; r.ra0 = r.ra1 = 0.0;
-  r.hl = r.hw = r.ca = r.sa = r.rad = 0.0;
   if (r.has_add) {
     Rect add{r.ax, r.ay, r.as, r.ar, r.aa};
     Geo g;
-    g.x = add.x; g.y = add.y; g.hl = g.hw = g.ca = g.sa = 0.0;
-    double rad = 0.0;
-    if (keep & KEEP_SIZE) { g.hl = L.hl[r.tslot]; g.hw = L.hw[r.tslot]; rad = L.rad[r.tslot]; }
-    else {
-      double length = (2.0 * add.s) / (1.0 + add.r), width = add.r * length;
-      g.hl = length / 2.0; g.hw = width / 2.0;
-      rad = geo_radius(g);
-    }
-    if (keep & KEEP_TRIG) { g.ca = L.ca[r.tslot]; g.sa = L.sa[r.tslot]; }
-    else if (keep & KEEP_EDGE_ANGLE) { g.ca = L.trig[r.acls]; g.sa = L.trig[MPP_NCLASS + r.acls]; }
-    else { double al = add.a + MPP_PI / 2.0; g.ca = cos(al); g.sa = sin(al); }
-    unit_part_mv<EXT>(P, c.t, mv, add, g, &r.lin_a, &r.gate_a, nullptr, false);
-    r.hl = g.hl; r.hw = g.hw; r.ca = g.ca; r.sa = g.sa; r.rad = rad;
+    g.x = add.x; g.y = add.y; g.hl = r.hl; g.hw = r.hw; g.ca = r.ca; g.sa = r.sa;
+    unit_part_mv<EXT>(P, c.t, mv, add, g, &r.lin_a, &r.gate_a, nullptr, false, contrast_pre);
   }
 }
 __device__ __forceinline__ void deep_post(const Chain &c, Rec &r, int n, double T, bool tracing) {
@@ -861,7 +870,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     //      otherwise -- or should a type have more than 64 steps -- the sorted steps are dealt to the waves in blocks.
     int es = e;
     mine = act0 && e < lim;
-    if (WAVES == 8 && by_type) {
+    if (WAVES == 8 && by_type && !EXT) {           // (EXT: the contrast terms are evaluated one rectangle at a time per wave -- equal shares)
       bool fits = true;
 #pragma unroll
       for (int k = 0; k < MPP_NKERNEL; ++k) {
@@ -876,6 +885,8 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
     }
     myoff = mine ? (int)D.poff[es] : 0;
     r.valid = 0; r.kernel = 0; r.accepted = 0; r.has_rem = r.has_add = 0; r.tslot = -1; r.tidx = -1;
+    int keep_x = 0;                                    // (EXT only: what deep_pre needs after the cooperative pass below)
+    MapVals pmv_x{0.f, 0.f, 0.f, 0.f, 0.0, 0.0, 0.0, 0};
     if (mine) {
       Tm = D.tring[(int)((done + myoff) & (long long)rmask)];
       r.valid = 1;
@@ -890,8 +901,33 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_deep_kernel(const DevPar
       DPH(3);
       if (r.kernel >= MPP_K_SPLIT) { r.valid = 0; r.kernel = -1; }
       if (r.valid && r.has_add && (r.ax < 0 || r.ax >= c.h.H || r.ay < 0 || r.ay >= c.h.W)) { r.valid = 0; r.kernel = -1; }
-      if (r.valid) deep_pre<EXT>(c, r, keep, tracing, pmv);
+      if (r.valid) {
+        deep_add_geo(c, r, keep);
+        if (!EXT) deep_pre<EXT>(c, r, keep, tracing, pmv, nullptr);
+      }
+      if (EXT) { keep_x = keep; pmv_x = pmv; }
     }
+    // the classic contrast term of every rectangle this wave's steps add: one rectangle at a time by the whole wave
+    // (csrc/mpp_classics.hpp: rows, then columns, across lanes), before the lanes go their own ways again
+    double cpre = 0.0;
+    bool have_cpre = false;
+    if (EXT) {
+      int cterm = -1;
+      for (int k = 0; k < P->model.n_unit; ++k) if (P->model.unit[k].kind == MPP_U_CONTRAST) cterm = k;
+      if (cterm >= 0) {
+        unsigned long long m = __ballot(mine && r.valid && r.has_add);
+        while (m) {
+          const int l = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          Geo g;
+          g.x = __builtin_amdgcn_readlane(r.ax, l); g.y = __builtin_amdgcn_readlane(r.ay, l);
+          g.hl = readlane_d(r.hl, l); g.hw = readlane_d(r.hw, l); g.ca = readlane_d(r.ca, l); g.sa = readlane_d(r.sa, l);
+          const double v = classic_contrast_wave(P->model.unit[cterm], c.t.img, c.t.img_c, c.h.H, c.h.W, g, c.lane);
+          if (c.lane == l) { cpre = v; have_cpre = true; }
+        }
+      }
+    }
+    if (EXT && mine && r.valid) deep_pre<EXT>(c, r, keep_x, tracing, pmv_x, have_cpre ? &cpre : nullptr);
     do_eval = mine && r.valid && (r.has_rem || r.has_add);
     DPH(4);
     }

@@ -263,10 +263,14 @@ __device__ __forceinline__ float map_mark(const MapVals &v, int k) {
 // `one_lane`: the whole wave asks for the same rectangle (the chain's wave mode): lane 0 alone walks the pixels -- the
 // rasteriser keeps its rows in private memory, 64 lanes doing the same would move 64 times the bytes -- and hands the
 // value to the others.
+// `contrast_pre`: the value of the rectangle's ContrastEnergy term, already computed by the whole wave
+// (classic_contrast_wave; the deep-round kernel evaluates the terms of its steps one rectangle at a time before the lanes
+// go their own ways).
 template <bool CL = false>
 __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const Geo &g, const MapVals &mv,
-                                    const TileRef &t, int H, int W, bool one_lane = false) {
+                                    const TileRef &t, int H, int W, bool one_lane = false, const double *contrast_pre = nullptr) {
   if (CL) {
+    if (u.kind == MPP_U_CONTRAST && contrast_pre) return *contrast_pre;
     if (u.kind == MPP_U_CONTRAST || u.kind == MPP_U_GRADIENT) {
       double v = 0.0;
       if (!one_lane || (threadIdx.x & 63) == 0)
@@ -321,19 +325,20 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
 // pixel and the marks, so that their latency overlaps the proposal densities and the trigonometry -- and without)
 template <bool CL = false>
 __device__ inline void unit_part_mv(const DevParams *P, const TileRef &t, const MapVals &mv, const Rect &q, const Geo &g,
-                                    double *lin, int *gate, double *vec_or_null, bool one_lane = false) {
+                                    double *lin, int *gate, double *vec_or_null, bool one_lane = false,
+                                    const double *contrast_pre = nullptr) {
   const mpp_model &M = P->model;
   const int H = P->H, W = P->W;
   // the gating term first (no local array: a runtime-indexed one would live in scratch memory)
   double vg = 0.0;
   int gt = 1;
   if (M.gate_term >= 0) {
-    vg = unit_value<CL>(M.unit[M.gate_term], q, g, mv, t, H, W, one_lane);
+    vg = unit_value<CL>(M.unit[M.gate_term], q, g, mv, t, H, W, one_lane, contrast_pre);
     gt = (vg <= M.gate_thr) ? 1 : 0;
   }
   double l = M.lin0;
   for (int k = 0; k < M.n_unit; ++k) {
-    double v = (k == M.gate_term) ? vg : unit_value<CL>(M.unit[k], q, g, mv, t, H, W, one_lane);
+    double v = (k == M.gate_term) ? vg : unit_value<CL>(M.unit[k], q, g, mv, t, H, W, one_lane, contrast_pre);
     if (vec_or_null) vec_or_null[k] = v;
     l += M.unit[k].coef * ((M.unit[k].gated ? (double)gt : 1.0)) * v;
   }

@@ -40,6 +40,17 @@ for size, n_rect, steps in ((96, 40, 20000), (512, 900, 30000)):
             ctx.run(steps, seed=2)
             ctx.synchronize()
             dt = time.perf_counter() - t0
-            out[f"{size}px_{ctype}_spec{spec}"] = {"proposals_per_s": steps / dt, "kernel_ms": ctx.last_kernel_ms(), "n_points": int(ctx.count(0))}
+            rec = {"proposals_per_s": steps / dt, "kernel_ms": ctx.last_kernel_ms(), "n_points": int(ctx.count(0))}
+            st = ctx.deep_stats()
+            if st.get("rounds"):
+                rec["deep_rounds"] = st["rounds"]
+                rec["steps_committed_per_round"] = st["committed"] / st["rounds"]
+                rec["steps_evaluated_per_round"] = st["evaluated"] / st["rounds"]
+                if os.environ.get("MPP_LIB_PATH", "").endswith("dprof.so"):      # per-phase clocks of the diagnostic build
+                    names = ["A:types", "A:bar1", "A:sort+bar2", "B:draw", "B:pre", "E:delta(total)", "B:post", "bar3", "C:decide+trace+ring",
+                             "D:apply-delta", "D:bar4", "D:mutate"]
+                    rec["phase_cycles_per_round"] = {f"wave{w}": {k: round(ctx.get_option(f"deep_stat{16 + 24 * w + i}") / st["rounds"])
+                                                                  for i, k in enumerate(names)} for w in range(spec)}
+            out[f"{size}px_{ctype}_spec{spec}"] = rec
             ctx.close()
 print(json.dumps(out, indent=1))
