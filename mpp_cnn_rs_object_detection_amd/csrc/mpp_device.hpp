@@ -260,9 +260,9 @@ __device__ __forceinline__ float map_mark(const MapVals &v, int k) {
 
 // one unit energy term of a rectangle.  CL: the classic image energies are compiled in (the chain kernel's extended
 // instantiations and the from-scratch kernels); elsewhere the host never selects a kernel for a model that has them.
-// `one_lane`: the whole wave asks for the same rectangle (the chain's wave mode): lane 0 alone walks the pixels -- the
-// rasteriser keeps its rows in private memory, 64 lanes doing the same would move 64 times the bytes -- and hands the
-// value to the others.
+// `one_lane`: the whole wave asks for the same rectangle (the chain's wave mode): the contrast term is then evaluated by
+// the wave together (classic_contrast_wave); the gradient term by lane 0 alone -- its outline lives in private memory, 64
+// lanes doing the same would move 64 times the bytes -- which hands the value to the others.
 // `contrast_pre`: the value of the rectangle's ContrastEnergy term, already computed by the whole wave
 // (classic_contrast_wave; the deep-round kernel evaluates the terms of its steps one rectangle at a time before the lanes
 // go their own ways).
@@ -271,6 +271,8 @@ __device__ inline double unit_value(const mpp_unit_term &u, const Rect &q, const
                                     const TileRef &t, int H, int W, bool one_lane = false, const double *contrast_pre = nullptr) {
   if (CL) {
     if (u.kind == MPP_U_CONTRAST && contrast_pre) return *contrast_pre;
+    // (wave mode: every lane is here with the same rectangle -- the wave works on it together)
+    if (u.kind == MPP_U_CONTRAST && one_lane) return classic_contrast_wave(u, t.img, t.img_c, H, W, g, (int)(threadIdx.x & 63));
     if (u.kind == MPP_U_CONTRAST || u.kind == MPP_U_GRADIENT) {
       double v = 0.0;
       if (!one_lane || (threadIdx.x & 63) == 0)
