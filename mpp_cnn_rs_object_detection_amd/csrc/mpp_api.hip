@@ -23,7 +23,9 @@ extern "C" hipError_t mpp_launch_deep(hipStream_t st, int waves, int occ, int gr
                                       unsigned long long seed, unsigned int chain0, int trace_tile, mpp_step_out *out,
                                       mpp_proposal *props, int nmax, int fixed_depth, int gain8, unsigned long long *stats, int ext);
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
-                                            double *dE, const int32_t *grid_start, const int32_t *grid_items);
+                                            double *dE, const int32_t *grid_start, const int32_t *grid_items, int sstride, int istride);
+extern "C" void mpp_launch_grid_build_all(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int ncell,
+                                          int cap, int32_t *start, int32_t *cursor, int32_t *items);
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
                                         int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                         double *ta, int32_t *n_removed);
@@ -88,6 +90,7 @@ struct mpp_ctx {
   bool img_borrowed = false;
   double *rowpart = nullptr, *rowbase = nullptr, *rowtot = nullptr, *boxsum = nullptr;
   bool box_dirty = true;
+  bool cdf_ready = false;          // rowpart / rowbase / boxsum exist (made by the first launch that draws births)
   int cap = 1024, cell_cap = 32, spec = 1, lanes = 0;
   // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
@@ -451,10 +454,9 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
       else HIPCHK(c, hipMemsetAsync(*dst[k], 0, cnt * sizeof(float), c->stream));
     }
   }
-  HIPCHK(c, dalloc(&c->rowpart, M * hw));
-  HIPCHK(c, dalloc(&c->rowbase, M * (H + 1)));
-  HIPCHK(c, dalloc(&c->rowtot, M * H));
-  HIPCHK(c, dalloc(&c->boxsum, M * hw));
+  // (the cumulative tables of the birth kernels -- 16 B per pixel -- are made by the first chain launch: a context that only
+  //  scores or merges, e.g. one whole 4096 x 4096 image, never needs them)
+  c->cdf_ready = false;
   c->box_dirty = true;
   HIPCHK(c, dalloc(&c->px, T * c->cap)); HIPCHK(c, dalloc(&c->py, T * c->cap));
   HIPCHK(c, dalloc(&c->ps, T * c->cap)); HIPCHK(c, dalloc(&c->pr, T * c->cap)); HIPCHK(c, dalloc(&c->pa, T * c->cap));
@@ -466,8 +468,6 @@ extern "C" int mpp_set_maps(mpp_ctx *c, int n_tiles, int H, int W, const float *
   std::vector<double> sched(T * 3);
   for (size_t t = 0; t < T; ++t) { sched[3 * t] = c->sched[0]; sched[3 * t + 1] = c->sched[1]; sched[3 * t + 2] = c->sched[2]; }
   HIPCHK(c, hipMemcpyAsync(c->T, sched.data(), sched.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  mpp_launch_cdf(c->stream, (int)M, c->det, H, W, c->rowpart, c->rowbase, c->rowtot);
-  HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((int)c->intensity.size() != c->n_tiles) c->intensity.assign(c->n_tiles, 1.0);
   c->have_maps = true;
@@ -528,9 +528,9 @@ static int push_state(mpp_ctx *c) {
       const size_t m = (size_t)(t % c->n_maps);                    // replica chains share their tile's maps
       r.det = (const MPP_GLOBAL float *)(c->det + m * hw);
       for (int k = 0; k < 3; ++k) r.m[k] = (const MPP_GLOBAL float *)(c->m[k] + m * hw * MPP_NCLASS);
-      r.rowpart = (const MPP_GLOBAL double *)(c->rowpart + m * hw);
-      r.rowbase = (const MPP_GLOBAL double *)(c->rowbase + m * (c->H + 1));
-      r.boxsum = (const MPP_GLOBAL double *)(c->boxsum + m * hw);
+      r.rowpart = c->cdf_ready ? (const MPP_GLOBAL double *)(c->rowpart + m * hw) : nullptr;
+      r.rowbase = c->cdf_ready ? (const MPP_GLOBAL double *)(c->rowbase + m * (c->H + 1)) : nullptr;
+      r.boxsum = c->cdf_ready ? (const MPP_GLOBAL double *)(c->boxsum + m * hw) : nullptr;
       for (int k = 0; k < 3; ++k)
         r.rm[k] = c->remap[k] ? (const MPP_GLOBAL double *)(c->remap[k] + m * hw * MPP_NCLASS) : nullptr;
       r.img = c->img ? (const MPP_GLOBAL float *)(c->img + m * hw * (size_t)c->img_c) : nullptr;
@@ -547,7 +547,7 @@ static int push_state(mpp_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tiles_dirty = false;
   }
-  if (c->box_dirty && c->have_kernels) {
+  if (c->box_dirty && c->have_kernels && c->cdf_ready) {
     const size_t hw = (size_t)c->H * c->W;
     (void)hw;
     mpp_launch_boxsum(c->stream, c->n_maps, c->rowpart, c->H, c->W, c->hp.kern.max_delta, c->boxsum);
@@ -831,7 +831,7 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int max_n = 0;
   for (int t = 0; t < T; ++t) max_n = n0[t] > max_n ? n0[t] : max_n;
-  if (max_n > MPP_MERGE_MAX_POINTS || c->cap > 65536)
+  if (max_n > MPP_MERGE_MAX_POINTS || (size_t)((c->cap + 7) & ~7) * 17 > (size_t)MPP_LDS_LIMIT - 256)      // (the walk's working set lives in LDS)
     return fail(c, -4, "merge_score: a tile holds %d points (the device walk takes at most %d): merge it on the host", max_n,
                 MPP_MERGE_MAX_POINTS);
   const size_t TC = (size_t)T * c->cap;
@@ -842,25 +842,26 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
   A((void **)&d_dE, TC * 8); A((void **)&ts, TC * 8); A((void **)&tr, TC * 8); A((void **)&ta, TC * 8);
   A((void **)&work, TC * 4); A((void **)&lst, TC * 4); A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
   std::vector<int32_t> h_rem(T, 0);
+  void *extra_free[3] = {nullptr, nullptr, nullptr};
   if (e == hipSuccess && max_n > 0) {
     const int dist2 = (int)floor(distance * distance + 1e-9);
-    // one image (T == 1, thousands of detections): the from-scratch energies look their neighbours up in the candidate grid
-    // (built on the device, again after the removals), as mpp_papangelou does
-    const int32_t *gs = nullptr, *gi = nullptr;
-    if (T == 1 && scratch_grid(c, 0, max_n, &gs, &gi)) e = hipErrorOutOfMemory;
-    if (e == hipSuccess) {
-      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, gs, gi);
-      mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
-      if (T == 1) {
-        e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e == hipSuccess && scratch_grid(c, 0, max_n - h_rem[0], &gs, &gi)) e = hipErrorOutOfMemory;
-      }
+    // the from-scratch energies look their neighbours up in per-tile candidate grids, built on the device before each of
+    // the two scorings (the removals in between move points)
+    const int ncell = c->hp.nx * c->hp.ny;
+    int32_t *gs = nullptr, *gc = nullptr, *gi = nullptr;
+    if (ncell > 0 && max_n >= 64) {
+      A((void **)&gs, (size_t)T * (ncell + 1) * 4); A((void **)&gc, (size_t)T * ncell * 4); A((void **)&gi, TC * 4);
     }
+    const bool grid = gs && gc && gi && e == hipSuccess;
     if (e == hipSuccess) {
-      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, gs, gi);
+      if (grid) mpp_launch_grid_build_all(c->stream, c->dp, c->d_tiles, T, max_n, ncell, c->cap, gs, gc, gi);
+      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, grid ? gs : nullptr, grid ? gi : nullptr, ncell + 1, c->cap);
+      mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
+      if (grid) mpp_launch_grid_build_all(c->stream, c->dp, c->d_tiles, T, max_n, ncell, c->cap, gs, gc, gi);
+      mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, grid ? gs : nullptr, grid ? gi : nullptr, ncell + 1, c->cap);
       e = hipGetLastError();
     }
+    extra_free[0] = gs; extra_free[1] = gc; extra_free[2] = gi;
     if (e == hipSuccess) e = hipMemcpyAsync(h_rem.data(), d_rem, sizeof(int32_t) * T, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
   }
@@ -873,7 +874,7 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
       for (int i = 0; i < n_out[t] && i < m; ++i) dE[(size_t)t * cap + i] = h[(size_t)t * m + i];
   }
   if (n_removed) for (int t = 0; t < T; ++t) n_removed[t] = h_rem[t];
-  void *fr[] = {d_dE, ts, tr, ta, work, lst, slot_of, tx, ty, d_rem};
+  void *fr[] = {d_dE, ts, tr, ta, work, lst, slot_of, tx, ty, d_rem, extra_free[0], extra_free[1], extra_free[2]};
   for (void *p : fr) if (p) (void)hipFree(p);
   HIPCHK(c, e);
   return rc;
@@ -991,12 +992,32 @@ static int ensure_remap_tables(mpp_ctx *c) {
   return 0;
 }
 
+// rowpart / rowbase (the two-level CDF of the detection map a data-driven birth is drawn from) and boxsum (window sums of
+// the translation kernel): made when the first chain is launched
+static int ensure_birth_tables(mpp_ctx *c) {
+  if (c->cdf_ready) return 0;
+  const size_t hw = (size_t)c->H * c->W, M = (size_t)c->n_maps;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, dalloc(&c->rowpart, M * hw));
+  HIPCHK(c, dalloc(&c->rowbase, M * (c->H + 1)));
+  HIPCHK(c, dalloc(&c->rowtot, M * c->H));
+  HIPCHK(c, dalloc(&c->boxsum, M * hw));
+  mpp_launch_cdf(c->stream, (int)M, c->det, c->H, c->W, c->rowpart, c->rowbase, c->rowtot);
+  HIPCHK(c, hipGetLastError());
+  c->cdf_ready = true;
+  c->box_dirty = true;
+  c->tiles_dirty = true;
+  return 0;
+}
+
 static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t seed, uint32_t chain0,
                      const mpp_proposal *d_tape, int trace_tile, mpp_step_out *d_out, mpp_proposal *d_props) {
   if (!c->have_kernels) return fail(c, -1, "mpp_set_kernels has not been called");
   if (!c->have_maps) return fail(c, -1, "mpp_set_maps has not been called");
   if (!c->have_model) return fail(c, -1, "mpp_set_model has not been called");
-  int rc = ensure_remap_tables(c);
+  int rc = ensure_birth_tables(c);
+  if (rc) return rc;
+  rc = ensure_remap_tables(c);
   if (rc) return rc;
   rc = push_state(c);
   if (rc) return rc;

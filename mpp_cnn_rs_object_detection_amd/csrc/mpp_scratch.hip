@@ -100,13 +100,16 @@ __device__ double point_energy(const DevParams *P, const TileRef &t, int n, cons
 }
 
 // ---- the grid: count, scan, fill, sort each cell (deterministic order) ------------------------------------------------
-__global__ void k_grid_count(const DevParams *P, const TileRef *tiles, int tile, int32_t *start) {
+// (blockIdx.y: the launch builds the grids of gridDim.y consecutive tiles, `sstride` / `istride` entries apart -- 1 tile: 0)
+__global__ void k_grid_count(const DevParams *P, const TileRef *tiles, int tile, int32_t *start, int sstride) {
+  tile += blockIdx.y; start += (size_t)blockIdx.y * sstride;
   TileRef t = tiles[tile];
   const int n = *t.n, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) atomicAdd(&start[1 + grid_coord(P, t.py[i]) + grid_coord(P, t.px[i]) * P->ny], 1);
 }
-__global__ __launch_bounds__(1024) void k_grid_scan(int32_t *start, int len) {       // inclusive scan in place, one workgroup
+__global__ __launch_bounds__(1024) void k_grid_scan(int32_t *start, int len, int sstride) {       // inclusive scan in place, one workgroup
   __shared__ int part[1024];
+  start += (size_t)blockIdx.y * sstride;
   const int per = (len + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, len);
   int s = 0;
   for (int i = lo; i < hi; ++i) s += start[i];
@@ -122,14 +125,17 @@ __global__ __launch_bounds__(1024) void k_grid_scan(int32_t *start, int len) {  
   for (int i = lo; i < hi; ++i) { run += start[i]; start[i] = run; }
 }
 __global__ void k_grid_fill(const DevParams *P, const TileRef *tiles, int tile, const int32_t *start, int32_t *cursor,
-                            int32_t *items) {
+                            int32_t *items, int sstride, int istride) {
+  tile += blockIdx.y; start += (size_t)blockIdx.y * sstride; cursor += (size_t)blockIdx.y * (sstride > 0 ? sstride - 1 : 0);
+  items += (size_t)blockIdx.y * istride;
   TileRef t = tiles[tile];
   const int n = *t.n, i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int c = grid_coord(P, t.py[i]) + grid_coord(P, t.px[i]) * P->ny;
   items[start[c] + atomicAdd(&cursor[c], 1)] = i;
 }
-__global__ void k_grid_sort(const int32_t *start, int32_t *items, int ncell) {
+__global__ void k_grid_sort(const int32_t *start, int32_t *items, int ncell, int sstride, int istride) {
+  start += (size_t)blockIdx.y * sstride; items += (size_t)blockIdx.y * istride;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= ncell) return;
   const int lo = start[c], hi = start[c + 1];
@@ -146,10 +152,22 @@ extern "C" void mpp_launch_grid_build(hipStream_t st, const DevParams *P, const 
   (void)hipMemsetAsync(start, 0, sizeof(int32_t) * ((size_t)ncell + 1), st);
   (void)hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)ncell, st);
   const unsigned gb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, P, tiles, tile, start);
-  hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, start, ncell + 1);
-  hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(256), 0, st, P, tiles, tile, (const int32_t *)start, cursor, items);
-  hipLaunchKernelGGL(k_grid_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, (const int32_t *)start, items, ncell);
+  hipLaunchKernelGGL(k_grid_count, dim3(gb), dim3(256), 0, st, P, tiles, tile, start, 0);
+  hipLaunchKernelGGL(k_grid_scan, dim3(1), dim3(1024), 0, st, start, ncell + 1, 0);
+  hipLaunchKernelGGL(k_grid_fill, dim3(gb), dim3(256), 0, st, P, tiles, tile, (const int32_t *)start, cursor, items, 0, 0);
+  hipLaunchKernelGGL(k_grid_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, (const int32_t *)start, items, ncell, 0, 0);
+}
+// the grids of tiles 0 .. n_tiles - 1 at once: start [n_tiles][ncell + 1], cursor [n_tiles][ncell], items [n_tiles][cap]
+extern "C" void mpp_launch_grid_build_all(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int ncell,
+                                          int cap, int32_t *start, int32_t *cursor, int32_t *items) {
+  (void)hipMemsetAsync(start, 0, sizeof(int32_t) * ((size_t)ncell + 1) * n_tiles, st);
+  (void)hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)ncell * n_tiles, st);
+  const unsigned gb = (unsigned)((max_n + 255) / 256);
+  hipLaunchKernelGGL(k_grid_count, dim3(gb, n_tiles), dim3(256), 0, st, P, tiles, 0, start, ncell + 1);
+  hipLaunchKernelGGL(k_grid_scan, dim3(1, n_tiles), dim3(1024), 0, st, start, ncell + 1, ncell + 1);
+  hipLaunchKernelGGL(k_grid_fill, dim3(gb, n_tiles), dim3(256), 0, st, P, tiles, 0, (const int32_t *)start, cursor, items, ncell + 1, cap);
+  hipLaunchKernelGGL(k_grid_sort, dim3((unsigned)((ncell + 255) / 256), n_tiles), dim3(256), 0, st, (const int32_t *)start, items, ncell,
+                     ncell + 1, cap);
 }
 
 __global__ void k_point_energies(const DevParams *P, const TileRef *tiles, int tile, double *e_pts, double *vectors, Grid g) {
@@ -211,15 +229,17 @@ __global__ __launch_bounds__(256) void k_delta_batch(const DevParams *P, const T
 
 // Papangelou of every point: dE[tile][i] = E(with u_i) - E(without u_i), i.e. minus the delta of removing it.  One wave per
 // point, the body of k_delta_batch with the one removal (same lanes, same reduction tree: the values of mpp_papangelou).
-// `g`: the candidate grid of tile 0 when the launch has ONE tile (a whole image's thousands of detections: without it every
-// point_energy below scans all of them), else {nullptr, nullptr}.
-__global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, const TileRef *tiles, int cap, double *dE, Grid g) {
+// `g0`: the candidate grids of the tiles, `sstride` / `istride` entries apart (without them every point_energy below scans
+// all points of its tile: 8 of the 17 ms a batch of 28 images took), or {nullptr, nullptr}.
+__global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, const TileRef *tiles, int cap, double *dE, Grid g0,
+                                                         int sstride, int istride) {
   __shared__ double part[64];
   __shared__ int32_t ex;
   const int tile = blockIdx.y, cs = blockIdx.x;
   TileRef t = tiles[tile];
   const int n = *t.n;
   if (cs >= n) return;
+  const Grid g{g0.start ? g0.start + (size_t)tile * sstride : nullptr, g0.items ? g0.items + (size_t)tile * istride : nullptr};
   if (threadIdx.x == 0) ex = cs;
   __syncthreads();
   Overlay o{1, &ex, 0, nullptr, nullptr};
@@ -279,11 +299,17 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
   const int tile = blockIdx.x, lane = threadIdx.x;
   TileRef t = tiles[tile];
   const int n = *t.n;
-  extern __shared__ unsigned char alive[];                     // [cap] flags (LDS: read in every inner loop)
+  // LDS: alive[cap] flags, then for the points that have a neighbour (ascending): index, packed position, score exp(-dE) --
+  // the walk reads them in every inner loop, and one wave alone hides no HBM latency (17 ms for a batch of 28 images when
+  // they sat in global memory)
+  extern __shared__ unsigned char dd_lds[];
+  unsigned char *alive = dd_lds;
+  const int cap8 = (cap + 7) & ~7;
+  int32_t *fj = (int32_t *)(dd_lds + cap8), *fxy = fj + cap8;
+  double *fsc = (double *)(fxy + cap8);
   int32_t *sl = slot_of + (size_t)tile * cap;
   const double *d = dE + (size_t)tile * cap;
   const int32_t *flags = work + (size_t)tile * cap;
-  int32_t *lst = lst_all + (size_t)tile * cap;                 // the points that have a neighbour, ascending
   const unsigned long long below = (1ull << lane) - 1ull;
   int nl = 0;
   for (int b = 0; b < n; b += WAVE) {
@@ -291,24 +317,27 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
     if (j < n) alive[j] = 1;
     const bool f = j < n && flags[j] != 0;
     const unsigned long long m = __ballot(f);
-    if (f) lst[nl + __popcll(m & below)] = j;
+    if (f) {
+      const int pos = nl + __popcll(m & below);
+      fj[pos] = j; fxy[pos] = (t.px[j] & 0xffff) | (t.py[j] << 16); fsc[pos] = exp(-d[j]);
+    }
     nl += __popcll(m);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   for (int li = 0; li < nl; ++li) {
-    const int i = lst[li];
+    const int i = fj[li];
     if (!alive[i]) continue;                                   // (uniform: every lane reads the same flag)
-    const int xi = t.px[i], yi = t.py[i];
+    const int xyi = fxy[li], xi = xyi & 0xffff, yi = (xyi >> 16) & 0xffff;
     // best score among the alive points within the distance (i itself is one of them)
     double top = -INFINITY;
     int first_nan = 0x7fffffff, cnt = 0;
     for (int lj = lane; lj < nl; lj += WAVE) {
-      const int j = lst[lj];
-      const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+      const int j = fj[lj], xy = fxy[lj];
+      const int dx = (xy & 0xffff) - xi, dy = ((xy >> 16) & 0xffff) - yi;
       if (alive[j] && dx * dx + dy * dy <= dist2) {
-        const double sc = exp(-d[j]);
+        const double sc = fsc[lj];
         ++cnt;
         if (sc != sc) first_nan = j < first_nan ? j : first_nan;
         else top = sc > top ? sc : top;
@@ -324,18 +353,18 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
     if (first_nan != 0x7fffffff) best = first_nan;             // numpy.argmax: the first NaN
     else {
       for (int lj = lane; lj < nl; lj += WAVE) {
-        const int j = lst[lj];
-        const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+        const int j = fj[lj], xy = fxy[lj];
+        const int dx = (xy & 0xffff) - xi, dy = ((xy >> 16) & 0xffff) - yi;
         if (alive[j] && dx * dx + dy * dy <= dist2) {
-          const double sc = exp(-d[j]);
+          const double sc = fsc[lj];
           if (finite ? sc >= thr : sc == top) best = j < best ? j : best;
         }
       }
       best = wave_min_i(best);
     }
     for (int lj = lane; lj < nl; lj += WAVE) {
-      const int j = lst[lj];
-      const int dx = t.px[j] - xi, dy = t.py[j] - yi;
+      const int j = fj[lj], xy = fxy[lj];
+      const int dx = (xy & 0xffff) - xi, dy = ((xy >> 16) & 0xffff) - yi;
       if (j != best && alive[j] && dx * dx + dy * dy <= dist2) alive[j] = 0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -376,17 +405,20 @@ __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int c
   }
 }
 extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int cap,
-                                            double *dE, const int32_t *grid_start, const int32_t *grid_items) {
+                                            double *dE, const int32_t *grid_start, const int32_t *grid_items, int sstride, int istride) {
   if (n_tiles <= 0 || max_n <= 0) return;
-  const Grid g = n_tiles == 1 ? Grid{grid_start, grid_items} : Grid{nullptr, nullptr};
-  hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE, g);
+  hipLaunchKernelGGL(k_papangelou_tiles, dim3(max_n, n_tiles), dim3(64), 0, st, P, tiles, cap, dE, Grid{grid_start, grid_items}, sstride,
+                     istride);
 }
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
                                         int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                         double *ta, int32_t *n_removed) {
   if (n_tiles <= 0) return;
   hipLaunchKernelGGL(k_has_neighbour, dim3((max_n + WAVE - 1) / WAVE, n_tiles), dim3(64), 0, st, tiles, cap, dist2, work);
-  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), (size_t)cap, st, tiles, cap, dE, dist2, (const int32_t *)work, lst, slot_of, tx, ty,
+  const size_t lds = (size_t)((cap + 7) & ~7) * 17;          // flags + (index, position, score) of the flagged points
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_dedupe_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
+  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), lds, st, tiles, cap, dE, dist2, (const int32_t *)work, lst, slot_of, tx, ty,
                      ts, tr, ta, n_removed);
 }
 

@@ -204,6 +204,8 @@ class ScoreMapNets:
         self.ctx = ctx or MppContext(device)
         self.fused = os.environ.get("MPP_UNET_UNFUSED", "0") != "1"
         self.mfma_conv = os.environ.get("MPP_UNET_MFMA_CONV", "1") != "0"      # csrc/mpp_conv.hip for the 32-channel level
+        self.two_streams = os.environ.get("MPP_UNET_TWO_STREAMS", "1") != "0"  # PosNet and ShapeNet on a stream each
+        self._streams = None
         # below this many pixels the forward is launch-bound and the plain nn.Module path (fewer host calls) is faster:
         # 512x512 3.4 ms vs 4.8 ms; 2048x2048 41 ms (nchw) / 36 ms (nhwc) float32, 31 / 15 ms bfloat16
         self.min_fused_pixels = 1 << 20
@@ -343,23 +345,49 @@ class ScoreMapNets:
         big = padded.shape[1] * padded.shape[2] >= self.min_fused_pixels
         if self.layout == "nhwc" and self.fused and big and padded.shape[1] >= 16 and padded.shape[2] >= 16:
             xi = padded.permute(1, 2, 0).contiguous().unsqueeze(0).permute(0, 3, 1, 2)      # [1,3,H,W] over NHWC memory
-            pos_out = self._cl(self._head(self.pos.final_layer, self._backbone_nhwc(self.pos.backbone, xi)))
-            h = self._backbone_nhwc(self.shp.backbone, xi)
             det = torch.empty((H, W), dtype=torch.float32, device=self.device)
             marks = [torch.empty((H, W, 32), dtype=torch.float32, device=self.device) for _ in range(3)]
-            self.ctx.posnet_epilogue_nhwc(pos_out, H, W, self.div_w, self.div_b, det)
-            heads = self._packed_heads()
-            if heads is not None and h.dtype == torch.float32:
-                # the three 1x1 heads, their biases and the softmax in ONE pass over h (csrc/mpp_conv.hip): 8.6 GB of
-                # traffic on a 4096 x 4096 image instead of 38 GB
-                h = self._cl(h)
-                self.ctx.shapenet_heads(h, heads[0], heads[1], H, W, marks)
-                self._keep = (pos_out, h)
+            cur = torch.cuda.current_stream(self.device)
+
+            def pos_part():
+                pos_out = self._cl(self._head(self.pos.final_layer, self._backbone_nhwc(self.pos.backbone, xi)))
+                self.ctx.posnet_epilogue_nhwc(pos_out, H, W, self.div_w, self.div_b, det)
+                return pos_out
+
+            def shp_part():
+                h = self._backbone_nhwc(self.shp.backbone, xi)
+                heads = self._packed_heads()
+                if heads is not None and h.dtype == torch.float32:
+                    # the three 1x1 heads, their biases and the softmax in ONE pass over h (csrc/mpp_conv.hip): 8.6 GB of
+                    # traffic on a 4096 x 4096 image instead of 38 GB
+                    h = self._cl(h)
+                    self.ctx.shapenet_heads(h, heads[0], heads[1], H, W, marks)
+                    return h
+                logits = [self._cl(self._head(fl[0], h)) for fl in self.shp.final_layers]
+                for k in range(3):
+                    self.ctx.shapenet_epilogue_nhwc(logits[k], H, W, marks[k])
+                return logits
+
+            if self.two_streams:
+                # the two networks are independent until the chains read both maps: PosNet on one stream, ShapeNet on
+                # another -- the tail of one network's kernel overlaps the head of the other's, launch gaps disappear
+                if self._streams is None:
+                    self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+                keep = []
+                for st, part in zip(self._streams, (pos_part, shp_part)):
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        self.ctx.set_stream(st.cuda_stream)
+                        keep.append(part())
+                for st in self._streams:
+                    cur.wait_stream(st)
+                self.ctx.set_stream(cur.cuda_stream)
+                for t in [det] + marks:
+                    for st in self._streams:
+                        t.record_stream(st)
+                self._keep = tuple(keep)
                 return det, marks
-            logits = [self._cl(self._head(fl[0], h)) for fl in self.shp.final_layers]
-            for k in range(3):
-                self.ctx.shapenet_epilogue_nhwc(logits[k], H, W, marks[k])
-            self._keep = (pos_out, logits)    # alive until the kernels on this stream have consumed them
+            self._keep = (pos_part(), shp_part())    # alive until the kernels on this stream have consumed them
             return det, marks
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             # (small images are launch-bound: there the extra host calls of the fused path cost more than its two

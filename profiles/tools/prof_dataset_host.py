@@ -24,5 +24,5 @@ for b in range(0, n_img, 28):
 pr.disable()
 print("total", time.perf_counter() - t0)
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(30)
 print(s.getvalue()[:9000])
