@@ -244,13 +244,51 @@ __global__ __launch_bounds__(64) void k_papangelou_tiles(const DevParams *P, con
   __syncthreads();
   Overlay o{1, &ex, 0, nullptr, nullptr};
   Overlay none{0, nullptr, 0, nullptr, nullptr};
+  // The points whose energy the removal changes -- u_cs itself and its neighbours within max_inter -- are listed first
+  // (ascending index), then every lane evaluates ONE of them: a dozen from-scratch energies side by side instead of one or
+  // two lanes working through them in seven turns.  The sum is then formed exactly as the plain loop below forms it (lane l
+  // adds the points l, l + 64, ... in that order, then the tree), so the values are those of k_delta_batch bit for bit.
+  constexpr int LIST = 256;
+  __shared__ int32_t lst[LIST];
+  __shared__ double val[LIST];
+  const int lane = threadIdx.x;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int cnt = 0;
+  for (int b = 0; b < n; b += 64) {
+    const int i = b + lane;
+    bool in = false;
+    if (i < n) {
+      const double dx = (double)(t.px[i] - t.px[cs]), dy = (double)(t.py[i] - t.py[cs]);
+      in = i == cs || sqrt(dx * dx + dy * dy) <= P->max_inter;
+    }
+    const unsigned long long m = __ballot(in);
+    const int pos = cnt + __popcll(m & below);
+    if (in && pos < LIST) lst[pos] = i;
+    cnt += __popcll(m);
+  }
+  __syncthreads();
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    Rect u = tile_rect(t, i);
-    if (i == cs) { acc -= point_energy(P, t, n, u, i, -1, none, nullptr, g); continue; }
-    double dx = (double)(u.x - t.px[cs]), dy = (double)(u.y - t.py[cs]);
-    if (sqrt(dx * dx + dy * dy) <= P->max_inter)
-      acc += point_energy(P, t, n, u, i, -1, o, nullptr, g) - point_energy(P, t, n, u, i, -1, none, nullptr, g);
+  if (cnt <= LIST) {
+    for (int k0 = 0; k0 < cnt; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < cnt) {
+        const int i = lst[k];
+        const Rect u = tile_rect(t, i);
+        val[k] = i == cs ? -point_energy(P, t, n, u, i, -1, none, nullptr, g)
+                         : point_energy(P, t, n, u, i, -1, o, nullptr, g) - point_energy(P, t, n, u, i, -1, none, nullptr, g);
+      }
+    }
+    __syncthreads();
+    for (int k = 0; k < cnt; ++k)
+      if ((lst[k] & 63) == lane) acc += val[k];
+  } else {                                              // (more than the list holds: the plain loop)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      Rect u = tile_rect(t, i);
+      if (i == cs) { acc -= point_energy(P, t, n, u, i, -1, none, nullptr, g); continue; }
+      double dx = (double)(u.x - t.px[cs]), dy = (double)(u.y - t.py[cs]);
+      if (sqrt(dx * dx + dy * dy) <= P->max_inter)
+        acc += point_energy(P, t, n, u, i, -1, o, nullptr, g) - point_energy(P, t, n, u, i, -1, none, nullptr, g);
+    }
   }
   part[threadIdx.x] = acc;
   __syncthreads();
