@@ -134,7 +134,8 @@ int mpp_synchronize(mpp_ctx *ctx);
  * round, the steps sorted by kernel type across the workgroup, neighbour energies evaluated by the whole wave for all its
  * steps at once (csrc/mpp_deep.hip); used for chains drawn from Philox under the shipped energy setups (overlap / max +
  * alignment / min pair terms, no split / merge, no classic image energy), others run one wave per step as before;
- * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; read-only "deep_stat0".."deep_stat3":
+ * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; "deep_gain" (8..64, default 12):
+ * the adaptive depth in eighths of the smoothed number of steps the last rounds committed; read-only "deep_stat0".."deep_stat3":
  * rounds, steps evaluated, rounds with a second pass, steps committed by the last mpp_run.  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per
  * 32-px cell, at most 64), "auto_grow" (default 1): a chain that would exceed either capacity stops BEFORE that step and
  * mpp_run / mpp_replay double the capacity (while the chain still fits the 160 KB of LDS) and continue it -- the reference's
@@ -271,6 +272,11 @@ int mpp_nhwc_glue(mpp_ctx *ctx, const void *x0, const void *x1, void *y, int H, 
  * NULL).  Reflect padding is index arithmetic (no padded copy).  All device pointers, the ctx's stream. */
 int mpp_conv3x3_c32(mpp_ctx *ctx, const float *x0, const float *x1, int H, int W, const float *wp, const float *in_scale,
                     const float *in_shift, const float *out_scale, const float *out_shift, int relu, float *y);
+
+/* The stem of a U-Net: Conv2d(3 -> 32, 3x3, padding_mode='reflect') + folded bias / BatchNorm + ReLU
+ * (model_parts/unet/unet_parts.py:12-31, first convolution of the first DoubleConv): x [H][W][3] float32 channels-last ->
+ * y [H][W][32] = max(0, conv * scale + shift); wp [9 taps][3 in][32 out].  Device pointers, the ctx's stream. */
+int mpp_conv3x3_stem(mpp_ctx *ctx, const float *x, int H, int W, const float *wp, const float *scale, const float *shift, float *y);
 
 /* ShapeNet's three 1x1 heads, their biases and the softmax in one pass (model_parts/shape_net.py:12-46,
  * shape_net_model.py's inference softmax): h [ldh][ldw][32] float32 channels-last (the backbone's output) ->

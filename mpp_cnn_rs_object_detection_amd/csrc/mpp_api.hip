@@ -49,6 +49,8 @@ extern "C" int mpp_launch_nhwc_glue(hipStream_t st, const void *x0, const void *
 extern "C" int mpp_launch_conv3x3_c32(hipStream_t st, const float *x0, const float *x1, int H, int W, const float *wp,
                                       const float *in_scale, const float *in_shift, const float *out_scale, const float *out_shift,
                                       int relu, float *y);
+extern "C" int mpp_launch_conv3x3_stem(hipStream_t st, const float *x, int H, int W, const float *wp, const float *scale,
+                                       const float *shift, float *y);
 extern "C" int mpp_launch_shapenet_heads(hipStream_t st, const float *h, int H, int W, int ldw, const float *wh, const float *bh,
                                          float *m0, float *m1, float *m2);
 extern "C" void mpp_launch_quad_iou(hipStream_t st, int n, const double *a, int m, const double *b, double *out);
@@ -95,7 +97,7 @@ struct mpp_ctx {
   // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
-  int deep = 128, deep_fixed = 0, deep_gain = 16;   // deep_gain / 8 x the steps the last rounds committed = depth of the next
+  int deep = 128, deep_fixed = 0, deep_gain = 12;   // deep_gain / 8 x the steps the last rounds committed = depth of the next (12: 4 % faster than 16 on the bench tile and on config 5's chains, 10 and 20 slower)
   unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
   int32_t *px = nullptr, *py = nullptr, *n = nullptr, *errd = nullptr;
@@ -175,7 +177,7 @@ static const char *chain_error_text(int e) {
 }
 
 // 2: ten kernels (split, merge), mpp_kernels.split_*; 3: mpp_nhwc_glue, mpp_*_epilogue_nhwc; 4: mpp_pack_detections; 5: mpp_set_chain_keys, options auto_grow / remap_table
-extern "C" int mpp_abi_version(void) { return 8; }
+extern "C" int mpp_abi_version(void) { return 9; }
 
 extern "C" void mpp_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
@@ -1222,6 +1224,14 @@ extern "C" int mpp_conv3x3_c32(mpp_ctx *c, const float *x0, const float *x1, int
   return 0;
 }
 
+extern "C" int mpp_conv3x3_stem(mpp_ctx *c, const float *x, int H, int W, const float *wp, const float *scale, const float *shift,
+                                float *y) {
+  if (!c || !x || !wp || !scale || !shift || !y || H < 2 || W < 2) return fail(c, -1, "bad conv3x3_stem arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (mpp_launch_conv3x3_stem(c->stream, x, H, W, wp, scale, shift, y))
+    return fail(c, -2, "conv3x3_stem launch failed (y must be 16-byte aligned): %s", hipGetErrorString(hipGetLastError()));
+  return 0;
+}
 extern "C" int mpp_shapenet_heads(mpp_ctx *c, int H, int W, int ldh, int ldw, const float *h, const float *w, const float *b,
                                   float *marks_size, float *marks_ratio, float *marks_angle) {
   if (!c || !h || !w || !b || !marks_size || !marks_ratio || !marks_angle || H < 1 || W < 1 || ldh < H || ldw < W)

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mpp_get_option", "mpp_set_maps", "mpp_set_image", "mpp_set_model", "mpp_set_kernels", "mpp_set_points", "mpp_get_points",
     "mpp_count", "mpp_get_points_all", "mpp_pack_detections", "mpp_total_energy", "mpp_delta_batch", "mpp_delta_vectors", "mpp_papangelou", "mpp_merge_score", "mpp_naive_init", "mpp_set_schedule",
     "mpp_replay", "mpp_run", "mpp_set_chain_keys", "mpp_step_index", "mpp_last_kernel_ms", "mpp_posnet_epilogue",
-    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_conv3x3_c32", "mpp_shapenet_heads", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
+    "mpp_shapenet_epilogue", "mpp_posnet_epilogue_nhwc", "mpp_shapenet_epilogue_nhwc", "mpp_affine_relu", "mpp_nhwc_glue", "mpp_conv3x3_c32", "mpp_conv3x3_stem", "mpp_shapenet_heads", "mpp_quad_iou", "mpp_philox4x32", "mpp_abi_version",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library(path: Optional[str] = None):
         "mpp_papangelou": (i32, [vp, i32, vp]),
         "mpp_conv3x3_c32": (i32, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
         "mpp_shapenet_heads": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+        "mpp_conv3x3_stem": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
         "mpp_merge_score": (i32, [vp, C.c_double, i32, vp, vp, vp, vp, vp]),
         "mpp_naive_init": (i32, [vp, dbl, dbl]),
         "mpp_set_schedule": (i32, [vp, dbl, dbl, dbl]),
@@ -537,6 +538,17 @@ class MppContext:
             out = torch.empty((1, h, w, 32), dtype=torch.float32, device=x0.device).permute(0, 3, 1, 2)
         self._check(self._L.mpp_conv3x3_c32(self._h, _ptr(x0), _ptr(x1), h, w, _ptr(wp), _ptr(in_scale), _ptr(in_shift),
                                             _ptr(out_scale), _ptr(out_shift), 1 if relu else 0, _ptr(out)))
+        return out
+
+    def conv3x3_stem(self, x, wp, scale, shift):
+        """Conv2d(3 -> 32, 3x3, reflect) + folded BatchNorm + ReLU of a U-Net's stem (``mpp_conv3x3_stem``): x [1,3,H,W] float32
+        with channels_last strides, wp [9,3,32]; returns a [1,32,H,W] channels_last tensor."""
+        import torch
+        h, w, c = nhwc_shape(x)
+        if c != 3 or x.dtype != torch.float32 or tuple(wp.shape) != (9, 3, 32):
+            raise ValueError("conv3x3_stem: a float32 channels-last picture of 3 channels, weights [9,3,32]")
+        out = torch.empty((1, h, w, 32), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        self._check(self._L.mpp_conv3x3_stem(self._h, _ptr(x), h, w, _ptr(wp), _ptr(scale), _ptr(shift), _ptr(out)))
         return out
 
     def shapenet_heads(self, h, w, b, H: int, W: int, marks):

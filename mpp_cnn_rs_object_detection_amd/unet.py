@@ -299,6 +299,13 @@ class ScoreMapNets:
         if c32 and seq[0].in_channels in (32, 64) and x0.shape[1] == 32 and (x1 is None) == (seq[0].in_channels == 32):
             h = self.ctx.conv3x3_c32(x0, self._packed(seq[0]), x1=x1, out_scale=s1, out_shift=t1)
             return self.ctx.conv3x3_c32(h, self._packed(seq[3]), out_scale=s2, out_shift=t2)
+        if c32 and x1 is None and seq[0].in_channels == 3 and x0.shape[1] == 3 and x0.dtype == torch.float32:
+            # the stem (3 -> 32): HBM-bound, one pass with its BatchNorm + ReLU (csrc/mpp_conv.hip: k_conv3x3_stem)
+            key = (id(seq[0]), "stem")
+            if key not in self._fold_cache:
+                self._fold_cache[key] = (seq[0].weight.detach().float().permute(2, 3, 1, 0).reshape(9, 3, 32).contiguous(),)
+            h = self.ctx.conv3x3_stem(x0, self._fold_cache[key][0], s1, t1)
+            return self.ctx.conv3x3_c32(h, self._packed(seq[3]), out_scale=s2, out_shift=t2)
         if c32 and x1 is None:                    # the stem (3 -> 32) by the library, its BatchNorm + ReLU at the next load
             y = self.ctx.nhwc_glue(x0, None, pad=1, pool=False, out_dtype=self.dtype)
             r = self._cl(F.conv2d(y, self._weights(seq[0])[0], None))

@@ -29,10 +29,11 @@ def run(self, *a, **k):
     return r
 hip_api.MppContext.run = run
 orig_init = hip_api.MppContext.__init__
-for deep in (128, 64, 32, 0):
-    def init(self, *a, _d=deep, **k):
+for deep, gain in ((128, 16), (128, 12), (128, 10), (64, 16), (64, 12), (0, 16)):
+    def init(self, *a, _d=deep, _g=gain, **k):
         orig_init(self, *a, **k)
         self.set_option("deep", _d)
+        self.set_option("deep_gain", _g)
     hip_api.MppContext.__init__ = init
     mpp.rng = np.random.default_rng(0)
     stats.clear()
@@ -40,4 +41,4 @@ for deep in (128, 64, 32, 0):
     st = dict(stats)
     ds = st.get("deep_stats") or {}
     st["committed_per_round"] = ds.get("committed", 0) / max(1, ds.get("rounds", 1))
-    print(json.dumps({"deep_option": deep, **st}), flush=True)
+    print(json.dumps({"deep_option": deep, "gain": gain, **st}), flush=True)

@@ -26,7 +26,7 @@ def test_library_exports_every_symbol(lib_path):
     L = ctypes.CDLL(lib_path)
     for name in hip_api.ABI_SYMBOLS:
         assert hasattr(L, name), name
-    assert L.mpp_abi_version() == 8
+    assert L.mpp_abi_version() == 9
 
 
 def test_struct_sizes_match_the_header(lib_path):

@@ -309,3 +309,26 @@ def test_fused_shapenet_heads_equal_convolutions_and_softmax(H, W, ldh, ldw):
     with pytest.raises(ValueError):
         ctx.shapenet_heads(h, w[:2], b, H, W, marks)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(64, 128), (37, 75), (17, 16), (130, 33)])
+def test_stem_convolution_equals_the_library_convolution(H, W):
+    """``mpp_conv3x3_stem`` (csrc/mpp_conv.hip): Conv2d(3 -> 32, 3x3, reflect) + folded BatchNorm + ReLU of the first
+    DoubleConv (unet_parts.py:12-31) in one pass over the picture -- against F.pad(mode='reflect') + F.conv2d in float32,
+    sizes that are not multiples of the 16 x 16 tiles included."""
+    import torch.nn.functional as F
+    from mpp_cnn_rs_object_detection_amd import hip_api
+    torch.manual_seed(H * 7 + W)
+    dev = torch.device("cuda", 0)
+    ctx = hip_api.MppContext(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    x = torch.rand((1, 3, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((32, 3, 3, 3), device=dev) / 5.0
+    sc, sh = torch.rand(32, device=dev) + 0.5, torch.randn(32, device=dev) * 0.1
+    got = ctx.conv3x3_stem(x, w.permute(2, 3, 1, 0).reshape(9, 3, 32).contiguous(), sc, sh)
+    torch.cuda.synchronize()
+    ref = torch.relu(F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    ctx.close()
