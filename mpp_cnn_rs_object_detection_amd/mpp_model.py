@@ -30,7 +30,7 @@ import numpy as np
 from . import distributed as mdist
 from . import energies as E
 from .custom_types import ImageWMaps
-from .data_loaders import (PATCH_SIZE, Detections, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps,
+from .data_loaders import (PATCH_SIZE, Detections, crop_image_w_maps, crop_region, distance_merge, load_image_w_maps, stack_tiles,
                            merge_patches, merge_score_images, tile_anchors)
 from .hip_api import MppError
 from .point_set import EPointsSet
@@ -312,11 +312,19 @@ class MPPModel:
         if region_data is None:
             region_data = self.region_maps(image_data, rank, world_size)
         origin = region_data.crop_data["tl_anchor"] if (region_data is not None and region_data.crop_data) else np.zeros(2, int)
-        tiles = []
-        for i in mine:
-            t = crop_image_w_maps(region_data, anchors[i] - origin, patch)
+        tiles, stacked = [], None
+        if world_size == 1 and len(mine) > 16 and not isinstance(self.energy_setup, E.ContrastMeasureEnergySetup):
+            # all tiles of the image at once (maps on the GPU, anchors on a regular grid): one strided copy per map
+            stacked = stack_tiles(region_data, [anchors[i] - origin for i in mine], patch)
+        for k, i in enumerate(mine):
+            if stacked is not None and k > 0:              # (tile 0 keeps real views: the energy setup looks at one tile)
+                t = ImageWMaps(image=None, name=region_data.name, shape=(patch, patch), detection_map=None, param_dist_maps=None,
+                               mappings=region_data.mappings, param_names=region_data.param_names, labels=None, gt_config=[])
+            else:
+                t = crop_image_w_maps(region_data, anchors[i] - origin, patch)
             t.crop_data = {"tl_anchor": np.array(anchors[i])}              # image coordinates, as merge_patches expects
             tiles.append(t)
+        self._stacked_maps = stacked
         start = time.perf_counter()
         sampler, buf, capacity = None, None, mdist.gather_capacity(n_tiles, world_size)
         if world_size > 1:
@@ -422,7 +430,9 @@ class MPPModel:
         """the local phase of ``infer_image``: this rank's tiles in one launch, their configurations packed for the gather"""
         start = time.perf_counter()
         sampler = TileBatchSampler(tiles, self.energy_setup, self.energy_model, device=self.device,
-                                   spec_waves=self.spec_waves, use_split_merge=bool(p.get("use_split_merge", False)))
+                                   spec_waves=self.spec_waves, use_split_merge=bool(p.get("use_split_merge", False)),
+                                   stacked_maps=getattr(self, "_stacked_maps", None))
+        self._stacked_maps = None
         sampler.init("naive")
         pack = None
         if world_size > 1:

@@ -84,7 +84,7 @@ class TileBatchSampler:
 
     def __init__(self, tiles: Sequence[ImageWMaps], energy_setup, energy_combinator, device: int = 0,
                  point_capacity: int = 1024, spec_waves: Optional[int] = 8, ctx: Optional[MppContext] = None,
-                 use_split_merge: bool = False, keys=None):
+                 use_split_merge: bool = False, keys=None, stacked_maps=None):
         """``keys`` = (seeds, chain ids), one per tile: the Philox key and chain id each tile's chain uses instead of the
         launch's seed and ``chain0 + tile`` -- tiles of several images in one launch keep the chains they would run in a
         launch of their own image (``mpp_set_chain_keys``)."""
@@ -102,7 +102,11 @@ class TileBatchSampler:
         auto_spec = spec_waves is None
         self.ctx = ctx or MppContext(device, point_capacity=point_capacity, spec_waves=8 if auto_spec else spec_waves)
         det0 = tiles[0].detection_map
-        if hasattr(det0, "data_ptr"):                 # maps already on the GPU (U-Net epilogue output)
+        if stacked_maps is not None:                  # (det [T,p,p], marks 3 x [T,p,p,32]) already stacked on the GPU
+            det, marks = stacked_maps
+            if int(det.shape[0]) != len(tiles):
+                raise ValueError("stacked_maps: one slice per tile")
+        elif hasattr(det0, "data_ptr"):                 # maps already on the GPU (U-Net epilogue output)
             import torch
             det = torch.stack([t.detection_map for t in tiles]).contiguous()
             marks = [torch.stack([t.param_dist_maps[k] for t in tiles]).contiguous() for k in range(3)]
