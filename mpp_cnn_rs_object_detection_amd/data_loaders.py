@@ -107,7 +107,7 @@ def crop_image_w_maps(image_data: ImageWMaps, tl_anchor: np.ndarray, patch_size:
                       crop_data={"tl_anchor": np.array([x, y])})
 
 
-def stack_tiles(image_data: ImageWMaps, anchors: Sequence[np.ndarray], patch_size: int):
+def stack_tiles(image_data: ImageWMaps, anchors: Sequence[np.ndarray], patch_size: int, require_cuda: bool = True):
     """The score maps of ALL tiles of an image as one tensor per map -- (det [T,p,p], marks 3 x [T,p,p,32]) -- in one strided
     copy each, for maps that are contiguous GPU tensors and anchors on a regular grid (``tile_anchors`` gives one whenever
     ``linspace`` lands on integers); None otherwise (the caller crops tile by tile).  256 tiles of a 4096 x 4096 image:
@@ -116,7 +116,9 @@ def stack_tiles(image_data: ImageWMaps, anchors: Sequence[np.ndarray], patch_siz
     marks = image_data.param_dist_maps
     if not hasattr(det, "as_strided") or image_data.labels is not None:
         return None
-    if not (det.is_cuda and det.is_contiguous() and all(m.is_cuda and m.is_contiguous() for m in marks)):
+    if not (det.is_contiguous() and all(hasattr(m, "as_strided") and m.is_contiguous() for m in marks)):
+        return None
+    if require_cuda and not (det.is_cuda and all(m.is_cuda for m in marks)):
         return None
     a = np.asarray(anchors, dtype=np.int64).reshape(-1, 2)
     xs, ys = np.unique(a[:, 0]), np.unique(a[:, 1])

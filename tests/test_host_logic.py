@@ -211,3 +211,37 @@ def test_distance_merge_tolerates_non_finite_scores():
     # ties within 1e-9: the first point wins
     removed = distance_merge(xy, np.array([1.0, 1.0 + 1e-12, 1.0 - 1e-12, 0.0]), 3.0)
     assert list(np.nonzero(~removed)[0]) == [0, 3]
+
+
+def test_stack_tiles_equals_tile_by_tile_crops():
+    """``data_loaders.stack_tiles``: the maps of all tiles of an image by one strided copy per map must be what
+    ``crop_image_w_maps`` cuts tile by tile (reference data_loaders.py:74-119 with the anchors of mpp_model.py:233-240) --
+    overlapping tiles included; anchors that are not on a regular grid, labelled images and numpy maps decline (None)."""
+    import torch
+    from mpp_cnn_rs_object_detection_amd import mappings
+    from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps
+    from mpp_cnn_rs_object_detection_amd.data_loaders import crop_image_w_maps, stack_tiles, tile_anchors
+    from mpp_cnn_rs_object_detection_amd.shapes import Rectangle
+    g = torch.Generator().manual_seed(0)
+    for H, W, p in ((96, 160, 32), (100, 100, 48), (64, 64, 64)):
+        det = torch.rand((H, W), generator=g)
+        marks = [torch.rand((H, W, 32), generator=g) for _ in range(3)]
+        data = ImageWMaps(name="0", shape=(H, W), image=None, detection_map=det, param_dist_maps=marks,
+                          mappings=mappings.default_mappings(), param_names=Rectangle.PARAMETERS, gt_config=[])
+        anchors = tile_anchors((H, W), p)
+        got = stack_tiles(data, anchors, p, require_cuda=False)
+        assert got is not None and tuple(got[0].shape) == (len(anchors), p, p)
+        for k, a in enumerate(anchors):
+            t = crop_image_w_maps(data, a, p)
+            assert torch.equal(got[0][k], t.detection_map)
+            for m in range(3):
+                assert torch.equal(got[1][m][k], t.param_dist_maps[m])
+        assert stack_tiles(data, anchors, p) is None                                     # host tensors: the caller crops
+    irregular = [np.array([0, 0]), np.array([0, 33]), np.array([0, 64]), np.array([31, 0]), np.array([31, 33]), np.array([31, 64])]
+    assert stack_tiles(data, irregular, 16, require_cuda=False) is None
+    assert stack_tiles(data, [np.array([0, 0]), np.array([0, 60])], 32, require_cuda=False) is None     # beyond the image
+    data.labels = {"centers": np.zeros((0, 2))}
+    assert stack_tiles(data, tile_anchors((64, 64), 32), 32, require_cuda=False) is None
+    data.labels = None
+    data.detection_map = det.numpy()
+    assert stack_tiles(data, tile_anchors((64, 64), 32), 32, require_cuda=False) is None
