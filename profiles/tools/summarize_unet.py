@@ -8,7 +8,11 @@ out = [f"# rocprofv3: the 4096 x 4096 float32 score-map forward ({TAG})", "",
        f"Source: `bash profiles/tools/pmc_unet4096.sh {TAG}` on one MI355X: `profiles/tools/prof_unet_4096.py` (PosNet + ShapeNet + epilogues, "
        "channels-last, random-init weights, 5 forwards per run), --kernel-trace --stats, then separate --pmc passes.", ""]
 try:
-    out += ["Bench line under the profiler: `" + open(f"{OUT}/bench.json").read().strip().splitlines()[-1] + "`", ""]
+    out += ["The forward as the product runs it (two streams, no profiler): `" + open(f"{OUT}/bench_two_streams.json").read().strip().splitlines()[-1] + "`", ""]
+except Exception:
+    pass
+try:
+    out += ["Bench line under the profiler (ONE stream, `MPP_UNET_TWO_STREAMS=0`, as are all tables below): `" + open(f"{OUT}/bench.json").read().strip().splitlines()[-1] + "`", ""]
 except Exception as e:
     out += [f"(no bench line: {e})", ""]
 # only the LAST 3 forwards count (the first passes pay MIOpen's algorithm search: naive reference convolutions and
