@@ -29,7 +29,7 @@ def run(self, *a, **k):
     return r
 hip_api.MppContext.run = run
 orig_init = hip_api.MppContext.__init__
-for deep, gain in ((128, 16), (128, 12), (128, 10), (64, 16), (64, 12), (0, 16)):
+for deep, gain in [(128, int(g)) for g in os.environ.get('PROBE_GAINS', '12,16').split(',')]:
     def init(self, *a, _d=deep, _g=gain, **k):
         orig_init(self, *a, **k)
         self.set_option("deep", _d)
