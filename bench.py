@@ -192,9 +192,13 @@ def main():
                 "valu_instructions_per_proposal": L["valu_instructions_per_proposal"],
                 "salu_instructions_per_proposal": L["salu_instructions_per_proposal"],
                 "exec_lanes_per_valu_cycle": L["exec_lanes_per_valu_cycle"],
-                "useful_lanes_note": "EXEC is wide (45 of 64 lanes on average) because wave-uniform work -- Philox, the draw, "
-                                     "densities, the Green ratio -- runs redundantly in every lane; lanes doing DISTINCT work: "
-                                     "one per candidate neighbour (~7 of 64) in eval_delta, 4-8 in the clipper, 1 elsewhere",
+                "useful_lanes_note": ("deep rounds: every active lane works on a DIFFERENT step (draw, densities, unit terms, Green "
+                                      "ratio) or a different (step, neighbour) pair; `exec_lanes_per_valu_cycle` therefore counts "
+                                      "distinct work, not the wave-uniform repetition it counted for the round-2 kernel (45 of 64)"
+                                      if "mpp_deep" in str(L.get("kernel", "")) else
+                                      "EXEC is wide because wave-uniform work -- Philox, the draw, densities, the Green ratio -- runs "
+                                      "redundantly in every lane; lanes doing DISTINCT work: one per candidate neighbour in eval_delta, "
+                                      "4-8 in the clipper, 1 elsewhere"),
                 "counters_source": lanes.get("source"), "counter_kernel": L["kernel"]}
 
     traffic, traffic_src, valu_busy = None, None, None

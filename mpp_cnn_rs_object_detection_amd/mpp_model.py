@@ -267,6 +267,10 @@ class MPPModel:
         if self.nets is None:
             raise ValueError("the image carries no score maps and no nets were given")
         det, marks = self.nets.infer_region(image_data.image, region)
+        # the chains read these maps from a stream of their own: the forward (two side streams joined on torch's current
+        # stream) must be complete first -- said here, not left to the default stream's implicit ordering
+        import torch
+        torch.cuda.current_stream(self.device).synchronize()
         x0, x1, y0, y1 = region
         img = image_data.image[x0:x1, y0:y1] if image_data.image is not None else None     # (the classic image energies read it)
         return ImageWMaps(image=img, name=image_data.name, shape=(x1 - x0, y1 - y0), detection_map=det,
