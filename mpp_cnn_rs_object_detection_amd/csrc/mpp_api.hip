@@ -27,7 +27,7 @@ extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, 
 extern "C" void mpp_launch_grid_build_all(hipStream_t st, const DevParams *P, const TileRef *tiles, int n_tiles, int max_n, int ncell,
                                           int cap, int32_t *start, int32_t *cursor, int32_t *items);
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
-                                        int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                         double *ta, int32_t *n_removed);
 extern "C" void mpp_launch_remap_table(hipStream_t st, const float *m, size_t n, double coef, double icpt, double *out);
 extern "C" void mpp_launch_set_until(hipStream_t st, const TileRef *tiles, int tile0, int n, long long n_steps, long long *until);
@@ -838,11 +838,11 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
                 MPP_MERGE_MAX_POINTS);
   const size_t TC = (size_t)T * c->cap;
   double *d_dE = nullptr, *ts = nullptr, *tr = nullptr, *ta = nullptr;
-  int32_t *work = nullptr, *lst = nullptr, *slot_of = nullptr, *tx = nullptr, *ty = nullptr, *d_rem = nullptr;
+  int32_t *work = nullptr, *slot_of = nullptr, *tx = nullptr, *ty = nullptr, *d_rem = nullptr;
   hipError_t e = hipSuccess;
   auto A = [&](void **p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 1); };
   A((void **)&d_dE, TC * 8); A((void **)&ts, TC * 8); A((void **)&tr, TC * 8); A((void **)&ta, TC * 8);
-  A((void **)&work, TC * 4); A((void **)&lst, TC * 4); A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
+  A((void **)&work, TC * 4); A((void **)&slot_of, TC * 4); A((void **)&tx, TC * 4); A((void **)&ty, TC * 4); A((void **)&d_rem, (size_t)T * 4);
   std::vector<int32_t> h_rem(T, 0);
   void *extra_free[3] = {nullptr, nullptr, nullptr};
   if (e == hipSuccess && max_n > 0) {
@@ -858,7 +858,7 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
     if (e == hipSuccess) {
       if (grid) mpp_launch_grid_build_all(c->stream, c->dp, c->d_tiles, T, max_n, ncell, c->cap, gs, gc, gi);
       mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, grid ? gs : nullptr, grid ? gi : nullptr, ncell + 1, c->cap);
-      mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, lst, slot_of, tx, ty, ts, tr, ta, d_rem);
+      mpp_launch_dedupe_tiles(c->stream, c->d_tiles, T, max_n, c->cap, d_dE, dist2, work, slot_of, tx, ty, ts, tr, ta, d_rem);
       if (grid) mpp_launch_grid_build_all(c->stream, c->dp, c->d_tiles, T, max_n, ncell, c->cap, gs, gc, gi);
       mpp_launch_papangelou_tiles(c->stream, c->dp, c->d_tiles, T, max_n, c->cap, d_dE, grid ? gs : nullptr, grid ? gi : nullptr, ncell + 1, c->cap);
       e = hipGetLastError();
@@ -876,7 +876,7 @@ extern "C" int mpp_merge_score(mpp_ctx *c, double distance, int cap, int32_t *n_
       for (int i = 0; i < n_out[t] && i < m; ++i) dE[(size_t)t * cap + i] = h[(size_t)t * m + i];
   }
   if (n_removed) for (int t = 0; t < T; ++t) n_removed[t] = h_rem[t];
-  void *fr[] = {d_dE, ts, tr, ta, work, lst, slot_of, tx, ty, d_rem, extra_free[0], extra_free[1], extra_free[2]};
+  void *fr[] = {d_dE, ts, tr, ta, work, slot_of, tx, ty, d_rem, extra_free[0], extra_free[1], extra_free[2]};
   for (void *p : fr) if (p) (void)hipFree(p);
   HIPCHK(c, e);
   return rc;

@@ -330,9 +330,9 @@ __global__ __launch_bounds__(64) void k_has_neighbour(const TileRef *tiles, int 
 // included), only the one with the best intensity exp(-dE) -- scores equal to 1e-9 are a tie and the first wins; a
 // non-finite best score: numpy's argmax (a NaN first, else the first infinity).  Then the removals in index order, each
 // moving the last point into the hole (EPointsSet.remove), which fixes the order of the survivors.  One wave per tile.
-// work: [T][cap] (alive flag, then the survivors' original indices); tmp*: [T][cap] copies of the configuration.
+// work: [T][cap] the neighbour flags of k_has_neighbour; slot_of, tx .. ta: [T][cap] scratch for the removals (permutation, then copies of the configuration).
 __global__ __launch_bounds__(64) void k_dedupe_tiles(const TileRef *tiles, int cap, const double *dE, int dist2, const int32_t *work,
-                                                     int32_t *lst_all, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                                     int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                                      double *ta, int32_t *n_removed) {
   const int tile = blockIdx.x, lane = threadIdx.x;
   TileRef t = tiles[tile];
@@ -449,14 +449,14 @@ extern "C" void mpp_launch_papangelou_tiles(hipStream_t st, const DevParams *P, 
                      istride);
 }
 extern "C" void mpp_launch_dedupe_tiles(hipStream_t st, const TileRef *tiles, int n_tiles, int max_n, int cap, const double *dE, int dist2,
-                                        int32_t *work, int32_t *lst, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
+                                        int32_t *work, int32_t *slot_of, int32_t *tx, int32_t *ty, double *ts, double *tr,
                                         double *ta, int32_t *n_removed) {
   if (n_tiles <= 0) return;
   hipLaunchKernelGGL(k_has_neighbour, dim3((max_n + WAVE - 1) / WAVE, n_tiles), dim3(64), 0, st, tiles, cap, dist2, work);
   const size_t lds = (size_t)((cap + 7) & ~7) * 17;          // flags + (index, position, score) of the flagged points
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_dedupe_tiles, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256); attr_set = true; }
-  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), lds, st, tiles, cap, dE, dist2, (const int32_t *)work, lst, slot_of, tx, ty,
+  hipLaunchKernelGGL(k_dedupe_tiles, dim3(n_tiles), dim3(64), lds, st, tiles, cap, dE, dist2, (const int32_t *)work, slot_of, tx, ty,
                      ts, tr, ta, n_removed);
 }
 
