@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from helpers import GOLDEN, hrc_model, log_model, sorted_rows
-from mpp_cnn_rs_object_detection_amd import mappings, synth
+from mpp_cnn_rs_object_detection_amd import hip_api, mappings, synth
 from mpp_cnn_rs_object_detection_amd.custom_types import ImageWMaps, Perturbation
 from mpp_cnn_rs_object_detection_amd.data_loaders import crop_image_w_maps, merge_patches, tile_anchors
 from mpp_cnn_rs_object_detection_amd.shapes import Rectangle
@@ -61,6 +61,30 @@ def test_device_merge_equals_the_reference_and_the_host_merge():
         det2, scores2 = res[1]
         assert len(det2) == len(det)
         np.testing.assert_allclose(np.sort(scores2), np.sort(scores), rtol=1e-12)
+
+
+def test_device_merge_declines_what_its_lds_does_not_hold():
+    """The dedupe walk keeps flags, positions and scores of a tile's points in LDS: a context whose point capacity exceeds
+    what 160 KB hold is refused with code -4 -- ``MPPModel.infer_image`` then merges on the host (``merge_patches``) --
+    and a capacity just below the limit works."""
+    from mpp_cnn_rs_object_detection_amd import energies as E
+    image = toy_image()
+    setup, comb = hrc_model()
+    unit, pair = setup.make_energies(image)
+    rows = Z["merge_in0"]
+    for cap, ok in ((9000, True), (12000, False)):
+        ctx = hip_api.MppContext(0, point_capacity=cap)
+        ctx.set_maps(np.asarray(image.detection_map, dtype=np.float32), [np.asarray(m, dtype=np.float32) for m in image.param_dist_maps])
+        ctx.set_model(E.build_model_desc(unit, pair, comb), image.mappings)
+        ctx.set_points(0, rows[:, :2].astype(np.int32), rows[:, 2:5].astype(np.float64))
+        if ok:
+            res, removed = ctx.merge_score(3)
+            assert len(res) == 1 and len(res[0][0]) == len(rows) - int(removed[0])
+        else:
+            with pytest.raises(hip_api.MppError) as ei:
+                ctx.merge_score(3)
+            assert ei.value.code == -4
+        ctx.close()
 
 
 @pytest.mark.parametrize("tag", ["log", "hrc"])
