@@ -234,6 +234,11 @@ def main():
         "traffic": traffic, "traffic_source": traffic_src, "traffic_unit": "bytes per launch",
         "algorithmic_bytes_per_launch": bpp * T * args.iters, "algorithmic_bytes_per_proposal": bpp,
         "kernel": "mpp_deep_kernel" if deep_stats else "mpp_chain_kernel", "kernel_ms": kernel_ms,
+        "kernel_note": ("a step of this bench = one chain of `iters` proposals = TWO launches since the hot start: mpp_chain_kernel (one "
+                        "wave per step) for the first proposals, until ~6 of 8 commit per round, then mpp_deep_kernel for the rest "
+                        f"({deep_stats['committed'] // max(1, T)} of {args.iters} here); `kernel_ms` = HIP-event time of "
+                        "both, which is what the rocprofv3 summary's two averages add up to") if deep_stats and deep_stats.get("committed", 0) and
+                       deep_stats["committed"] < T * args.iters else None,
         "issue": issue, "occupied_cu_valu_busy_frac": valu_busy,
         "note": "one chain = one workgroup (8 waves) = 1 of 256 CUs: `frac` prices it against the whole chip's HBM roof as SURVEY "
                 "8(d) asks; `issue.frac_of_the_simds_in_use` is the share of instruction issue slots of the 4 SIMDs it runs on; "

@@ -134,6 +134,8 @@ int mpp_synchronize(mpp_ctx *ctx);
  * round, the steps sorted by kernel type across the workgroup, neighbour energies evaluated by the whole wave for all its
  * steps at once (csrc/mpp_deep.hip); used for chains drawn from Philox under the shipped energy setups (overlap / max +
  * alignment / min pair terms, no split / merge, no classic image energy), others run one wave per step as before;
+ * "handover" (default 1): a chain of 8 waves starts with one wave per step and is handed to the deep rounds once about 6 of
+ * 8 steps commit per round (a hot chain changes its state every few steps: short rounds suit it better); same chain;
  * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; "deep_gain" (8..64, default 12):
  * the adaptive depth in eighths of the smoothed number of steps the last rounds committed; read-only "deep_stat0".."deep_stat3":
  * rounds, steps evaluated, rounds with a second pass, steps committed by the last mpp_run.  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per

@@ -97,6 +97,7 @@ struct mpp_ctx {
   // deep rounds (mpp_deep.hip): every lane of the chain's `spec` waves evaluates one step, at most `deep` steps per round
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
+  int handover = 1;                  // start a chain of 8 waves with one wave per step and hand it to the deep rounds once it has cooled down
   int deep = 128, deep_fixed = 0, deep_gain = 12;   // deep_gain / 8 x the steps the last rounds committed = depth of the next (12: 4 % faster than 16 on the bench tile and on config 5's chains, 10 and 20 slower)
   unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
@@ -264,6 +265,9 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else if (!strcmp(name, "deep")) {
     if (v != 0 && (v < 8 || v > 256 || (v & (v - 1)))) return fail(c, -1, "deep must be 0 or a power of two in 8..256");
     c->deep = (int)v;
+  } else if (!strcmp(name, "handover")) {
+    if (v != 0 && v != 1) return fail(c, -1, "handover must be 0 or 1");
+    c->handover = (int)v;
   } else if (!strcmp(name, "deep_gain")) {
     if ((v & 0xff) < 8 || (v & 0xff) > 64 || (v & ~0x1ffll)) return fail(c, -1, "deep_gain must be in 8..64 (eighths; + 256: sorted steps dealt in blocks)");
     c->deep_gain = (int)v;
@@ -315,6 +319,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "replicas")) return c->replicas;
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
+  if (!strcmp(name, "handover")) return c->handover;
   if (!strcmp(name, "auto_grow")) return c->auto_grow;
   if (!strcmp(name, "remap_table")) return c->remap[0] ? 1 : 0;       // are the tables in use right now?
   if (!strcmp(name, "grow_events")) return c->grow_events;
@@ -1057,6 +1062,11 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   c->last_ms = 0.0;
   // many chains in one launch: prefer the instantiation that lets two waves share a SIMD
   const int occ = (grid >= 1024) ? 2 : 1;
+  // hot start: one wave per step until the chain has cooled down (ERR_HANDOVER), then deep rounds -- the same chain either way
+  // (launches of a few chains only: the launch that hands over ends when its LAST chain has cooled down, the others' CUs idle
+  //  until then -- 256 tiles of config 5's scene lost 3 ms to that, one tile gains 6)
+  bool hot_start = deep_nmax > 0 && c->handover && c->spec == 8 && c->lanes == 0 && trace_tile < 0 && !c->deep_fixed && n_steps >= 4096 &&
+                   grid <= 16 && chain_lds_total(c, c->cap, c->cell_cap) <= MPP_LDS_LIMIT;
   for (;;) {
     size_t lds = chain_lds(c, c->cap, c->cell_cap);
     // deep rounds need room for their step reports next to the chain state: halve the round until it fits, or do without
@@ -1067,6 +1077,9 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
       nmax /= 2;
     if (nmax < c->spec || nmax < 8) nmax = 0;
     if (c->cell_cap > 64) nmax = 0;        // (the deep kernel lists a cell's candidates in a 64-bit mask: fuller cells run one step per wave)
+    if (hot_start && nmax > 0) nmax = 0;
+    else hot_start = false;
+    if (c->hp.handover != (hot_start ? 1 : 0)) { c->hp.handover = hot_start ? 1 : 0; c->params_dirty = true; if ((rc = push_state(c))) return rc; }
     if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_);
     else if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",
@@ -1088,11 +1101,17 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     c->last_ms += ms;
     std::vector<int32_t> herr(grid);
     HIPCHK(c, hipMemcpy(herr.data(), c->errd + tile0, grid * sizeof(int32_t), hipMemcpyDeviceToHost));
-    bool cell = false, point = false;
+    bool cell = false, point = false, cooled = false;
     for (int t = 0; t < grid; ++t) {
       if (herr[t] == 1) cell = true;
       else if (herr[t] == 2) point = true;
+      else if (herr[t] == 5) cooled = true;
       else if (herr[t]) return fail(c, -10 - herr[t], "tile %d: %s", tile0 + t, chain_error_text(herr[t]));
+    }
+    if (cooled) {                          // (a launch that ended for a capacity as well grows first and keeps its hot start)
+      for (int t = 0; t < grid; ++t) if (herr[t] == 5) herr[t] = 0;
+      HIPCHK(c, hipMemcpy(c->errd + tile0, herr.data(), grid * sizeof(int32_t), hipMemcpyHostToDevice));
+      if (!cell && !point) { hot_start = false; continue; }
     }
     if (!cell && !point) return 0;
     const bool can_grow = c->auto_grow != 0;

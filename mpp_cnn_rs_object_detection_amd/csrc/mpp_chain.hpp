@@ -33,6 +33,7 @@
 #define ERR_POINT_OVERFLOW 2
 #define ERR_BAD_TARGET 3
 #define ERR_CAND_OVERFLOW 4
+#define ERR_HANDOVER 5        // not an error: the chain has cooled down (see DevParams::handover)
 
 #ifdef MPP_PROFILE
 // diagnostic build only: cycles per phase of wave 0, summed over the launch (never in the product build)

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
   unsigned long long prof_[16] = {0};
 #endif
 
+  int ho_ema = 0, ho_rounds = 0;                // (the commit wave) steps committed per round, x 256, smoothed; rounds so far
   while (done < n_steps && err == 0) {
     const int n = __builtin_amdgcn_readfirstlane(L.sh[0]);
     double T = *(double *)(L.sh + 4);
@@ -343,6 +344,15 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
           cur = w + 1;
         }
         for (int i = 0; i < committed; ++i) if (Tc > T_target) Tc *= alpha;      // rjmcmc.py:158-159
+        // A hot chain changes its state every few steps: rounds of 8 speculative steps (26 k cycles) suit it better than deep
+        // rounds (45 k cycles and more, whatever commits).  Once ~6 of 8 steps commit per round -- a step changes the state
+        // with probability below ~0.1 -- the chain is handed to the deep-round kernel: this launch ends after the round's
+        // commits, like a capacity stop, and the host continues with the very next step.
+        if (P->handover && !apply_round) {
+          ho_ema += ((committed << 8) - ho_ema) / 16;
+          ++ho_rounds;
+          if (err == 0 && ho_rounds >= 48 && ho_ema >= 1408 && done + committed < n_steps) err = ERR_HANDOVER;
+        }
         if (c.lane == 0) {
           L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; L.sh[3] = (int)commit_mask; *(double *)(L.sh + 4) = Tc;
           if (apply_round) L.sh[6] = 0;

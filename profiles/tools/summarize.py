@@ -18,20 +18,24 @@ for p in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         out.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | "
                    f"{float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.3f} |")
     out.append("")
-out += ["## PMC (mean per dispatch of the chain kernel; separate passes)", "", "| counter | mean per launch |", "|---|---|"]
+out += ["## PMC (mean per CHAIN of the bench -- a chain that starts hot is two launches, mpp_chain_kernel then mpp_deep_kernel: "
+        "their counters are added; separate passes)", "", "| counter | mean per chain |", "|---|---|"]
 vals = {}
 for p in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
-    agg = collections.defaultdict(list)
+    agg = collections.defaultdict(float)
+    chains = collections.defaultdict(set)
     for r in csv.DictReader(open(p)):
         if ("mpp_chain" in r["Kernel_Name"] or "mpp_deep" in r["Kernel_Name"]):
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            if "mpp_deep" in r["Kernel_Name"]:
+                chains[r["Counter_Name"]].add(r["Dispatch_Id"])
     for k, v in agg.items():
-        vals[k] = sum(v) / len(v)
+        vals[k] = v / max(1, len(chains[k]))
         out.append(f"| {k} | {vals[k]:.6g} |")
 out.append("")
 if "FETCH_SIZE" in vals:
     # guide: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream
-    out += [f"HBM traffic per launch: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB (x2 gfx950 correction for wide streams = "
+    out += [f"HBM traffic per chain: FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB (x2 gfx950 correction for wide streams = "
             f"{2*vals['FETCH_SIZE']/1024:.1f} MiB upper figure), WRITE_SIZE {vals.get('WRITE_SIZE', 0):.0f} KiB.", ""]
 bj = os.path.join(src, "bench_trace.json")
 if os.path.exists(bj) and os.path.getsize(bj):

@@ -65,3 +65,28 @@ def test_deep_chain_matches_oracle():
     oxy, om = o.get_points()
     np.testing.assert_array_equal(gxy, oxy)
     np.testing.assert_allclose(gm, om, rtol=1e-9, atol=1e-9)
+
+
+def test_hot_start_hands_the_chain_over_without_changing_it():
+    """A chain of 8 waves starts with one wave per step and is handed to the deep rounds once ~6 of 8 steps commit per
+    round (``handover``, csrc/mpp_sampler.hip: ERR_HANDOVER; the launch ends after a round's commits like a capacity
+    stop and ``mpp_run`` continues with the next step): the final configuration, the step counter and the temperature
+    are those of the chain run in deep rounds alone and with one wave per step alone; the deep rounds did the rest."""
+    n_steps, seed = 30000, 11
+    finals = []
+    for handover, deep in ((1, 128), (0, 128), (0, 0)):
+        t, o, ctx = setup_case(256, 80, "legacy", spec=8)
+        ctx.set_option("deep", deep)
+        ctx.set_option("handover", handover)
+        ctx.set_schedule(1.0, 0.999, 0.0)
+        ctx.run(n_steps, seed)
+        st = ctx.deep_stats()
+        if handover:
+            assert 0 < st["committed"] < n_steps, st          # both kernels took part
+        elif deep:
+            assert st["committed"] == n_steps
+        assert ctx.step_index() == n_steps
+        finals.append(ctx.get_points())
+        ctx.close()
+    for xy, m in finals[1:]:
+        assert xy.tobytes() == finals[0][0].tobytes() and m.tobytes() == finals[0][1].tobytes()
