@@ -136,6 +136,8 @@ int mpp_synchronize(mpp_ctx *ctx);
  * alignment / min pair terms, no split / merge, no classic image energy), others run one wave per step as before;
  * "handover" (default 1): a chain of 8 waves starts with one wave per step and is handed to the deep rounds once about 6 of
  * 8 steps commit per round (a hot chain changes its state every few steps: short rounds suit it better); same chain;
+ * "handover_tiles" (default 64): only launches of at most this many chains start that way (the launch that hands over
+ * ends when its last chain has cooled down);
  * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; "deep_gain" (8..64, default 12):
  * the adaptive depth in eighths of the smoothed number of steps the last rounds committed; read-only "deep_stat0".."deep_stat3":
  * rounds, steps evaluated, rounds with a second pass, steps committed by the last mpp_run.  The chain is identical for every setting. "point_capacity": slots per tile (before mpp_set_maps), "cell_capacity" (points per

@@ -98,6 +98,7 @@ struct mpp_ctx {
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
   int handover = 1;                  // start a chain of 8 waves with one wave per step and hand it to the deep rounds once it has cooled down
+  int handover_tiles = 64;           // ... in launches of at most this many chains (64 tiles of config 4: -6 %; 256 of config 5: +4 %)
   int deep = 128, deep_fixed = 0, deep_gain = 12;   // deep_gain / 8 x the steps the last rounds committed = depth of the next (12: 4 % faster than 16 on the bench tile and on config 5's chains, 10 and 20 slower)
   unsigned long long *deep_stats = nullptr;
   int replicas = 1, n_maps = 0;      // n_tiles = n_maps * replicas chains; chain t samples on the maps of tile t % n_maps
@@ -268,6 +269,9 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else if (!strcmp(name, "handover")) {
     if (v != 0 && v != 1) return fail(c, -1, "handover must be 0 or 1");
     c->handover = (int)v;
+  } else if (!strcmp(name, "handover_tiles")) {
+    if (v < 1 || v > 65536) return fail(c, -1, "handover_tiles must be in 1..65536");
+    c->handover_tiles = (int)v;
   } else if (!strcmp(name, "deep_gain")) {
     if ((v & 0xff) < 8 || (v & 0xff) > 64 || (v & ~0x1ffll)) return fail(c, -1, "deep_gain must be in 8..64 (eighths; + 256: sorted steps dealt in blocks)");
     c->deep_gain = (int)v;
@@ -320,6 +324,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "n_chains")) return c->n_tiles;
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "handover")) return c->handover;
+  if (!strcmp(name, "handover_tiles")) return c->handover_tiles;
   if (!strcmp(name, "auto_grow")) return c->auto_grow;
   if (!strcmp(name, "remap_table")) return c->remap[0] ? 1 : 0;       // are the tables in use right now?
   if (!strcmp(name, "grow_events")) return c->grow_events;
@@ -1066,7 +1071,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
   // (launches of a few chains only: the launch that hands over ends when its LAST chain has cooled down, the others' CUs idle
   //  until then -- 256 tiles of config 5's scene lost 3 ms to that, one tile gains 6)
   bool hot_start = deep_nmax > 0 && c->handover && c->spec == 8 && c->lanes == 0 && trace_tile < 0 && !c->deep_fixed && n_steps >= 4096 &&
-                   grid <= 16 && chain_lds_total(c, c->cap, c->cell_cap) <= MPP_LDS_LIMIT;
+                   grid <= c->handover_tiles && chain_lds_total(c, c->cap, c->cell_cap) <= MPP_LDS_LIMIT;
   for (;;) {
     size_t lds = chain_lds(c, c->cap, c->cell_cap);
     // deep rounds need room for their step reports next to the chain state: halve the round until it fits, or do without

@@ -223,6 +223,8 @@ class MppContext:
             self.set_option("replicas", replicas)
         if deep is not None:
             self.set_option("deep", deep)
+        if os.environ.get("MPP_HANDOVER_TILES"):           # (experiments: the largest launch that starts hot)
+            self.set_option("handover_tiles", int(os.environ["MPP_HANDOVER_TILES"]))
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
