@@ -35,16 +35,22 @@ def deps():
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps()):
         return LIB
-    objs = []
+    objs, todo = [], []
     for src in sources():
         obj = os.path.splitext(src)[0] + ".o"
         if force or not os.path.exists(obj) or any(os.path.getmtime(obj) < os.path.getmtime(d)
                                                    for d in [src] + deps()[len(sources()):]):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+            todo.append([HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj])
+        objs.append(obj)
+    if todo:                                            # (the two chain-kernel files take 1.5 minutes each: side by side)
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(4, len(todo))) as pool:
+            list(pool.map(run, todo))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
