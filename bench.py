@@ -235,7 +235,7 @@ def main():
         "algorithmic_bytes_per_launch": bpp * T * args.iters, "algorithmic_bytes_per_proposal": bpp,
         "kernel": "mpp_deep_kernel" if deep_stats else "mpp_chain_kernel", "kernel_ms": kernel_ms,
         "kernel_note": ("a step of this bench = one chain of `iters` proposals = TWO launches since the hot start: mpp_chain_kernel (one "
-                        "wave per step) for the first proposals, until ~6 of 8 commit per round, then mpp_deep_kernel for the rest "
+                        "wave per step) for the first proposals, until ~5 of 8 commit per round, then mpp_deep_kernel for the rest "
                         f"({deep_stats['committed'] // max(1, T)} of {args.iters} here); `kernel_ms` = HIP-event time of "
                         "both, which is what the rocprofv3 summary's two averages add up to") if deep_stats and deep_stats.get("committed", 0) and
                        deep_stats["committed"] < T * args.iters else None,

@@ -136,6 +136,7 @@ int mpp_synchronize(mpp_ctx *ctx);
  * alignment / min pair terms, no split / merge, no classic image energy), others run one wave per step as before;
  * "handover" (default 1): a chain of 8 waves starts with one wave per step and is handed to the deep rounds once about 6 of
  * 8 steps commit per round (a hot chain changes its state every few steps: short rounds suit it better); same chain;
+ * "handover_at" (default 1280): that number of steps committed per round, x 256;
  * "handover_tiles" (default 64): only launches of at most this many chains start that way (the launch that hands over
  * ends when its last chain has cooled down);
  * "deep_fixed" (tests): a fixed number of steps per round instead of the adaptive depth; "deep_gain" (8..64, default 12):

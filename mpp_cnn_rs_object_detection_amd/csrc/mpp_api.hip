@@ -98,6 +98,7 @@ struct mpp_ctx {
   // (default 128; 0 = off: one wave per step); deep_fixed > 0 pins the number of steps per round (tests); deep_stats: rounds, evaluated
   // steps, rounds with a change, committed steps of the last mpp_run (device counters, read on request)
   int handover = 1;                  // start a chain of 8 waves with one wave per step and hand it to the deep rounds once it has cooled down
+  int handover_at = 1280;            // ... when the smoothed steps committed per round of 8 reach this / 256 (5.0: one tile is flat from 4.5 to 6.5, 64 tiles want it early -- 34.8 ms at 5.0, 36.3 at 5.5, 42 at 6.5)
   int handover_tiles = 64;           // ... in launches of at most this many chains (64 tiles of config 4: -6 %; 256 of config 5: +4 %)
   int deep = 128, deep_fixed = 0, deep_gain = 12;   // deep_gain / 8 x the steps the last rounds committed = depth of the next (12: 4 % faster than 16 on the bench tile and on config 5's chains, 10 and 20 slower)
   unsigned long long *deep_stats = nullptr;
@@ -269,6 +270,9 @@ extern "C" int mpp_set_option(mpp_ctx *c, const char *name, int64_t v) {
   } else if (!strcmp(name, "handover")) {
     if (v != 0 && v != 1) return fail(c, -1, "handover must be 0 or 1");
     c->handover = (int)v;
+  } else if (!strcmp(name, "handover_at")) {
+    if (v < 256 || v > 2048) return fail(c, -1, "handover_at must be in 256..2048 (steps committed per round of 8, x 256)");
+    c->handover_at = (int)v;
   } else if (!strcmp(name, "handover_tiles")) {
     if (v < 1 || v > 65536) return fail(c, -1, "handover_tiles must be in 1..65536");
     c->handover_tiles = (int)v;
@@ -325,6 +329,7 @@ extern "C" int64_t mpp_get_option(mpp_ctx *c, const char *name) {
   if (!strcmp(name, "cell_capacity")) return c->cell_cap;
   if (!strcmp(name, "handover")) return c->handover;
   if (!strcmp(name, "handover_tiles")) return c->handover_tiles;
+  if (!strcmp(name, "handover_at")) return c->handover_at;
   if (!strcmp(name, "auto_grow")) return c->auto_grow;
   if (!strcmp(name, "remap_table")) return c->remap[0] ? 1 : 0;       // are the tables in use right now?
   if (!strcmp(name, "grow_events")) return c->grow_events;
@@ -1084,7 +1089,7 @@ static int run_chain(mpp_ctx *c, int grid, int tile0, int64_t n_steps, uint64_t 
     if (c->cell_cap > 64) nmax = 0;        // (the deep kernel lists a cell's candidates in a 64-bit mask: fuller cells run one step per wave)
     if (hot_start && nmax > 0) nmax = 0;
     else hot_start = false;
-    if (c->hp.handover != (hot_start ? 1 : 0)) { c->hp.handover = hot_start ? 1 : 0; c->params_dirty = true; if ((rc = push_state(c))) return rc; }
+    if (c->hp.handover != (hot_start ? c->handover_at : 0)) { c->hp.handover = hot_start ? c->handover_at : 0; c->params_dirty = true; if ((rc = push_state(c))) return rc; }
     if (nmax > 0) lds = mpp_deep_lds_bytes(c->cap, ncell_, c->cell_cap, rb_, c->spec, nmax, ext_);
     else if (chain_lds_total(c, c->cap, c->cell_cap) > MPP_LDS_LIMIT)
       return fail(c, -7, "chain state needs %zu B of LDS (> %d): lower point_capacity/cell_capacity/spec_waves or tile size",

@@ -37,8 +37,9 @@ struct DevParams {
   int32_t n_kernels;    // 8, or 10 when the split / merge kernels carry probability
   int32_t rowbase_lds;  // the birth CDF's row level ([H+1] doubles) is staged in LDS (set per launch by the host)
   int32_t force_accept; // apply every proposal (perturbation_sampler.py:162-166 walks kernels without accept/reject)
-  int32_t handover;     // (one wave per step, 8 waves) stop with ERR_HANDOVER once ~6 of 8 steps commit per round: the host then
-                        // continues the chain in deep rounds (set per launch by the host)
+  int32_t handover;     // (one wave per step, 8 waves) > 0: stop with ERR_HANDOVER once the smoothed number of steps committed
+                        // per round reaches handover / 256 (~6 of 8): the host then continues the chain in deep rounds (set per
+                        // launch by the host)
   double inv_step[3];   // 32 / (vmax - vmin)
 };
 

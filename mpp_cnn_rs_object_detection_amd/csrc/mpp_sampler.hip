@@ -345,13 +345,13 @@ __global__ __launch_bounds__(WAVE *WAVES, OCC) void mpp_chain_kernel(const DevPa
         }
         for (int i = 0; i < committed; ++i) if (Tc > T_target) Tc *= alpha;      // rjmcmc.py:158-159
         // A hot chain changes its state every few steps: rounds of 8 speculative steps (26 k cycles) suit it better than deep
-        // rounds (45 k cycles and more, whatever commits).  Once ~6 of 8 steps commit per round -- a step changes the state
-        // with probability below ~0.1 -- the chain is handed to the deep-round kernel: this launch ends after the round's
+        // rounds (45 k cycles and more, whatever commits).  Once handover / 256 (5 by default) of 8 steps commit per round -- a step
+        // changes the state with probability below ~0.12 -- the chain is handed to the deep-round kernel: this launch ends after the round's
         // commits, like a capacity stop, and the host continues with the very next step.
         if (P->handover && !apply_round) {
           ho_ema += ((committed << 8) - ho_ema) / 16;
           ++ho_rounds;
-          if (err == 0 && ho_rounds >= 48 && ho_ema >= 1408 && done + committed < n_steps) err = ERR_HANDOVER;
+          if (err == 0 && ho_rounds >= 48 && ho_ema >= P->handover && done + committed < n_steps) err = ERR_HANDOVER;
         }
         if (c.lane == 0) {
           L.sh[0] = cur_n; L.sh[1] = err; L.sh[2] = committed; L.sh[3] = (int)commit_mask; *(double *)(L.sh + 4) = Tc;

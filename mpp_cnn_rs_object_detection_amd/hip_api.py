@@ -225,6 +225,8 @@ class MppContext:
             self.set_option("deep", deep)
         if os.environ.get("MPP_HANDOVER_TILES"):           # (experiments: the largest launch that starts hot)
             self.set_option("handover_tiles", int(os.environ["MPP_HANDOVER_TILES"]))
+        if os.environ.get("MPP_HANDOVER_AT"):
+            self.set_option("handover_at", int(os.environ["MPP_HANDOVER_AT"]))
 
     # -- plumbing ------------------------------------------------------------------------------
     def _check(self, rc: int):
